@@ -1,0 +1,192 @@
+/*
+ * sempyr.h — C ABI of libsempyr_hip.so: the MI355X (gfx950) operator backend for the
+ * Semantic-Pyramid GAN training / synthesis hot path.
+ *
+ * The reference (tomer1727/Semantic_Pyramid_for_image_generation) has no FFI of its own:
+ * its operator backend is whatever `torch.nn` dispatches to (SURVEY.md §8b "lower face").
+ * Every entry point below therefore cites the reference call site whose torch operator it
+ * replaces (file:line relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - return 0 = OK; <0 = invalid descriptor / unsupported shape (never a silent fallback);
+ *     >0 = hipError_t of a failed launch. sempyr_last_error_string() describes the last failure.
+ *   - plain pointers and sizes only; all device buffers (workspace included) are owned by the
+ *     caller; nothing is allocated or freed here; no host synchronisation; kernels are enqueued
+ *     on the hipStream_t passed as `void* stream` (0 = the null stream).
+ *   - tensors are fp32, NCHW, contiguous. Element counts must be < 2^31.
+ *   - stateless and re-entrant (the autograd worker thread calls the backward entry points).
+ */
+#ifndef SEMPYR_H
+#define SEMPYR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEMPYR_ERR_INVALID (-1)
+#define SEMPYR_ABI_VERSION 1
+
+int sempyr_version(void);
+const char* sempyr_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family (implicit-GEMM on v_mfma_f32_32x32x2_f32).
+ *
+ * One descriptor describes a torch.nn.Conv2d: input B x Cin x Hin x Win (optionally seen through
+ * a fused nearest x2 upsample, ups=1), weight Cout x Cin x kh x kw, stride, padding.
+ * A torch.nn.ConvTranspose2d(Cin_t, Cout_t) is the *dgrad* of the Conv2d(Cout_t -> Cin_t) with the
+ * same weight tensor, so it uses the same three primitives with the roles swapped.
+ *
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d forward and (double-)backward at
+ *   generator.py:23-25,115,119 ; discriminator.py:37,98,101,115 ; classifier.py:33,37-40,43
+ *   (torchvision resnet18 convs and fc) ; featuresCreatorGen.py:13,67 ; and
+ *   nn.UpsamplingNearest2d(2) generator.py:44,78 when ups=1.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sempyr_conv_desc {
+    int32_t B, Cin, Hin, Win;   /* physical input (pre-upsample) */
+    int32_t Cout, kh, kw;
+    int32_t stride, pad;
+    int32_t ups;                /* 1: the conv reads nearest-x2-upsampled input (2Hin x 2Win) */
+} sempyr_conv_desc;
+
+enum { SEMPYR_CONV_FWD = 0, SEMPYR_CONV_DGRAD = 1, SEMPYR_CONV_WGRAD = 2 };
+
+#define SEMPYR_CONV_MAX_PHASES 4
+
+typedef struct sempyr_conv_plan {
+    int32_t mode;
+    int32_t Ho, Wo;                 /* conv output spatial dims */
+    int32_t nphases;                /* 1 for FWD/WGRAD; stride^2 for DGRAD */
+    int32_t K[SEMPYR_CONV_MAX_PHASES];      /* GEMM reduction length per phase (0 = phase has no taps) */
+    int32_t Kpad[SEMPYR_CONV_MAX_PHASES];   /* padded to the k-chunk */
+    int32_t tab_off[SEMPYR_CONV_MAX_PHASES];/* offset (entries) of the phase in the k-table */
+    int32_t tab_entries;            /* total k-table entries (each = 2 int32 gather + 1 int32 weight src) */
+    int32_t Mpad;                   /* packed-weight row length */
+    int64_t wpack_floats;           /* size of the packed weight buffer (FWD, DGRAD), 0 for WGRAD */
+    int64_t workspace_bytes;        /* split-K slabs */
+    int32_t splits[SEMPYR_CONV_MAX_PHASES];
+    int32_t cfg;                    /* tile configuration chosen */
+} sempyr_conv_plan;
+
+/* Shape inference + launch plan (host only, no GPU needed). */
+int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_conv_plan* plan);
+
+/* Host-side fill of the gather table (2*tab_entries int32: channel offset, packed dy/dx) and of the
+ * weight-source table (tab_entries int32) for FWD or DGRAD. WGRAD uses the FWD gather table. */
+int sempyr_conv2d_tables(const sempyr_conv_desc* d, int mode, int32_t* ktab_host, int32_t* wsrc_host);
+
+/* Re-layout torch weights (Cout,Cin,kh,kw) into the k-major GEMM operand used by FWD / DGRAD. */
+int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, const float* w,
+                               const int32_t* wsrc_dev, float* wpacked, void* stream);
+
+/* y[B,Cout,Ho,Wo] = conv(x, w) (+ bias[Cout] if bias != NULL). */
+int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wpacked_fwd,
+                      const int32_t* ktab_fwd_dev, const float* bias, float* y,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a
+ * ConvTranspose2d whose forward this is). With ups=1 the result is the gradient in the upsampled
+ * domain; reduce it with sempyr_sumpool2. */
+int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, const float* wpacked_dgrad,
+                        const int32_t* ktab_dgrad_dev, const float* bias, float* gx,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* gw[Cout,Cin,kh,kw] = sum_{b,oy,ox} gy * x (deterministic split-K, fixed summation order). */
+int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, const float* x,
+                        const int32_t* ktab_fwd_dev, float* gw,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation: BatchNorm2d (train) / InstanceNorm2d(affine) / GroupNorm(1,C)
+ * Tensors are seen as rows = N*C of len = H*W. `rowbuf` receives four per-row arrays
+ * [mean_row | rstd_row | scale_row | shift_row] (each N*C floats); apply them with
+ * sempyr_affine_act. Replaces nn.BatchNorm2d generator.py:28, and get_norm_layer
+ * discriminator.py:16-26 (+ their autograd backward and double backward used by the gradient
+ * penalty train_model.py:69-76).
+ * ---------------------------------------------------------------------------------------- */
+enum { SEMPYR_NORM_BATCH = 0, SEMPYR_NORM_INSTANCE = 1, SEMPYR_NORM_LAYER = 2 };
+enum { SEMPYR_ACT_NONE = 0, SEMPYR_ACT_RELU = 1, SEMPYR_ACT_LRELU = 2, SEMPYR_ACT_TANH = 3 };
+
+/* scratch: 2*N*C floats. running_mean/var/num_batches_tracked (BATCH only) may be NULL. */
+int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
+                      const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                      float* rowbuf, float* scratch, void* stream);
+
+/* eval-mode BatchNorm2d (classifier.py:34 with .eval(), train_model.py:153): per-row scale/shift
+ * from the running statistics. */
+int sempyr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, int N, int C,
+                          float* scale_row, float* shift_row, void* stream);
+
+/* (gx, ggamma, gbeta) of y = act(norm(x)); y is needed only when act != NONE. scratch: 5*N*C floats.
+ * ggamma / gbeta may be NULL. */
+int sempyr_norm_bwd(int kind, const float* gy, const float* y, const float* x, const float* gamma,
+                    const float* mean_row, const float* rstd_row, int N, int C, int HW,
+                    int act, float slope, float* gx, float* ggamma, float* gbeta,
+                    float* scratch, void* stream);
+
+/* Backward of sempyr_norm_bwd's gx output: given u = dL/d(gx) returns dL/d(gy), dL/dx, dL/dgamma
+ * (g_gamma may be NULL). scratch: 14*N*C floats. */
+int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, const float* y, const float* x,
+                        const float* gamma, const float* mean_row, const float* rstd_row,
+                        int N, int C, int HW, int act, float slope,
+                        float* g_gy, float* g_x, float* g_gamma, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise (HBM-bound) kernels.
+ * ---------------------------------------------------------------------------------------- */
+/* y = act(x*scale_row[r] + shift_row[r] + res); scale/shift (both or neither) and res optional.
+ * Replaces norm apply + nn.ReLU/LeakyReLU/Tanh (generator.py:29,48,57,120; discriminator.py:39,56,
+ * 99,102) and the residual adds generator.py:56,87 ; discriminator.py:63. */
+int sempyr_affine_act(const float* x, const float* scale_row, const float* shift_row, const float* res,
+                      float* y, int rows, int len, int act, float slope, void* stream);
+/* g' = gy*act'(y); gx = g'*scale_row (NULL -> 1), gres = g' ; either output may be NULL. */
+int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_row, float* gx, float* gres,
+                          int rows, int len, int act, float slope, void* stream);
+/* y = a*b : features[i]*masks[i] generator.py:126-129, train_model.py:219-221 */
+int sempyr_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* y = alpha*a + beta*b (b may be NULL) : gradient accumulation / scaling glue */
+int sempyr_axpby(const float* a, const float* b, float alpha, float beta, float* y, int64_t n, void* stream);
+/* out = real + alpha_row[r]*(fake-real) : sample_line train_model.py:51-55 */
+int sempyr_lerp_rows(const float* real, const float* fake, const float* alpha_row, float* out,
+                     int rows, int len, void* stream);
+/* transforms.Normalize train_model.py:240-245 : y=(x-mean_c)/std_c ; backward!=0: y = x/std_c */
+int sempyr_normalize(const float* x, const float* mean_c, const float* std_c, float* y,
+                     int N, int C, int HW, int backward, void* stream);
+/* y[r][h][w] = scale*sum 2x2 : nn.AvgPool2d(2) (scale .25) discriminator.py:57,103 ; upsample backward (scale 1) */
+int sempyr_pool2_down(const float* x, float* y, int rows, int H, int W, float scale, void* stream);
+/* y[r][2h+a][2w+b] = scale*x[r][h][w] : nn.UpsamplingNearest2d(2) generator.py:44 ; avg-pool backward (scale .25) */
+int sempyr_pool2_up(const float* x, float* y, int rows, int h, int w, float scale, void* stream);
+/* nn.MaxPool2d(3, 2, 1) of the ResNet18 stem classifier.py:36 ; idx = argmax offsets for the backward */
+int sempyr_maxpool3s2_fwd(const float* x, float* y, int32_t* idx, int rows, int H, int W, void* stream);
+int sempyr_maxpool3s2_bwd(const float* gy, const int32_t* idx, float* gx, int rows, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss-path reductions (deterministic). `scratch` = sempyr_reduce_scratch_floats() floats unless
+ * stated. Scalar outputs/inputs live on the device (no host sync).
+ * ---------------------------------------------------------------------------------------- */
+int sempyr_reduce_scratch_floats(void);
+/* *out = scale * mean(x) : d_loss_fn / g_loss_fn train_model.py:39-46 */
+int sempyr_mean(const float* x, int64_t n, float scale, float* out, float* scratch, void* stream);
+/* y[i] = scale * (*g) : backward of a mean */
+int sempyr_fill_scalar(const float* g, float scale, float* y, int64_t n, void* stream);
+/* *out = mean |a*m - b*m| (mask NULL -> |a-b|) : nn.L1Loss train_model.py:219-221,109 */
+int sempyr_l1_mean(const float* a, const float* b, const float* mask, int64_t n, float* out, float* scratch, void* stream);
+int sempyr_l1_mean_bwd(const float* a, const float* b, const float* mask, const float* gout, int64_t n,
+                       float* ga, float* gb, void* stream);
+/* norms[r] = ||grad[r,:]||_2 ; *gp = mean (norms-1)^2 : norm + one_mean_gp train_model.py:58-66 */
+int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, void* stream);
+/* out = grad * (*gout) * (2/rows) * (norm-1)/norm : its backward (feeds the double backward) */
+int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int rows, int len, float* out, void* stream);
+/* out[c] = scale * sum_{n,hw} x[n][c][hw] : conv bias gradient ; scratch = N*C floats */
+int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, float* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMPYR_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libsempyr_hip.so (the C ABI declared in include/sempyr.h).
+
+The product path has no CPU fallback: if the shared library is missing or does not export a
+declared symbol, importing this module raises.  Only loading / symbol resolution happens here
+(no GPU needed); compute entry points are only called by `ops.py` on CUDA(HIP) tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsempyr_hip.so")
+
+c_int, c_float, c_void_p, c_int64, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_size_t)
+
+MAX_PHASES = 4
+CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+NORM_BATCH, NORM_INSTANCE, NORM_LAYER = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Hin", ctypes.c_int32), ("Win", ctypes.c_int32),
+                ("Cout", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("ups", ctypes.c_int32)]
+
+
+class ConvPlanInfo(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
+                ("nphases", ctypes.c_int32),
+                ("K", ctypes.c_int32 * MAX_PHASES), ("Kpad", ctypes.c_int32 * MAX_PHASES),
+                ("tab_off", ctypes.c_int32 * MAX_PHASES), ("tab_entries", ctypes.c_int32),
+                ("Mpad", ctypes.c_int32), ("wpack_floats", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64),
+                ("splits", ctypes.c_int32 * MAX_PHASES), ("cfg", ctypes.c_int32)]
+
+
+_P = c_void_p  # every device / host pointer is passed as an integer address
+_DESC = ctypes.POINTER(ConvDesc)
+
+# name -> argtypes ; every function returns int except where noted. Mirrors include/sempyr.h 1:1
+# (tests/test_abi.py parses the header and checks this table against it).
+SIGNATURES = {
+    "sempyr_version": [],
+    "sempyr_conv2d_plan": [_DESC, c_int, ctypes.POINTER(ConvPlanInfo)],
+    "sempyr_conv2d_tables": [_DESC, c_int, _P, _P],
+    "sempyr_conv2d_pack_weights": [_DESC, c_int, _P, _P, _P, _P],
+    "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
+    "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
+    "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, _P, c_size_t, _P],
+    "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, _P, _P],
+    "sempyr_bn_eval_coeffs": [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P],
+    "sempyr_norm_bwd": [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
+    "sempyr_norm_bwd_bwd": [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
+    "sempyr_affine_act": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_affine_act_bwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_mul": [_P, _P, _P, c_int64, _P],
+    "sempyr_axpby": [_P, _P, c_float, c_float, _P, c_int64, _P],
+    "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],
+    "sempyr_normalize": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "sempyr_pool2_down": [_P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_pool2_up": [_P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_maxpool3s2_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "sempyr_maxpool3s2_bwd": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "sempyr_reduce_scratch_floats": [],
+    "sempyr_mean": [_P, c_int64, c_float, _P, _P, _P],
+    "sempyr_fill_scalar": [_P, c_float, _P, c_int64, _P],
+    "sempyr_l1_mean": [_P, _P, _P, c_int64, _P, _P, _P],
+    "sempyr_l1_mean_bwd": [_P, _P, _P, _P, c_int64, _P, _P, _P],
+    "sempyr_gp_fwd": [_P, c_int, c_int, _P, _P, _P],
+    "sempyr_gp_bwd": [_P, _P, _P, c_int, c_int, _P, _P],
+    "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, _P, _P],
+}
+
+
+class SempyrError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C semantic_pyramid_for_image_generation_amd/csrc`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.sempyr_last_error_string.argtypes = []
+    lib.sempyr_last_error_string.restype = ctypes.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    """Raise on a non-zero return code of an entry point (never continue silently)."""
+    if rc != 0:
+        msg = lib.sempyr_last_error_string().decode("utf-8", "replace")
+        raise SempyrError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,33 @@
+// Shared helpers for the sempyr HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sempyr.h"
+
+// Error bookkeeping: every entry point returns 0 on success, <0 for an invalid
+// descriptor / unsupported shape (never a silent fallback), >0 for a hipError_t.
+void sempyr_set_error(const char* fmt, ...);
+
+#define SEMPYR_FAIL(...) do { sempyr_set_error(__VA_ARGS__); return SEMPYR_ERR_INVALID; } while (0)
+#define SEMPYR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) { sempyr_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return (int)e_; } } while (0)
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// wave64 sum reduction (all lanes get the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block (256 threads = 4 waves) sum; result valid in every thread. `sh` needs >= 4 floats.
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}

@@ -1,0 +1,699 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (64-lane wavefronts, 4 waves per workgroup).
+//
+// One kernel template serves the three primitives every Conv2d / ConvTranspose2d of the
+// reference decomposes into (generator.py:23-25, discriminator.py:37, classifier.py:33-43):
+//
+//   FWD    C[m=co][n=(b,oy,ox)]  = sum_k Wp[k=(tap,ci)][m] * x[b][ci][oy*s-p+ky][ox*s-p+kx]
+//   DGRAD  C[m=ci][n=(b,qy,qx)]  = sum_k Wp[k=(tap',co)][m] * gy[b][co][qy+cy-j][qx+cx-i]   (per stride phase)
+//   WGRAD  C[m=co][n=(tap,ci)]   = sum_{k=(b,oy,ox)} gy[b][co][oy][ox] * x[b][ci][oy*s-p+ky][ox*s-p+kx]
+//
+// The activation operand is gathered straight from the NCHW tensor through a small k-table
+// (channel offset + packed dy/dx per reduction index), optionally through a fused nearest-x2
+// upsample (coordinate >> 1). Weights are re-laid k-major once per optimizer step so the weight
+// tile is a plain 2-D copy. Tiles are staged in LDS as [k][m] / [k][n]; a lane's MFMA operand is
+// the dword at [k0 + lane/32][tile + lane%32], i.e. 32 consecutive banks per half-wave: no
+// bank conflicts and no swizzle needed for the one-dword-per-lane f32 operands.
+// Split-K partial tiles go to caller-provided slabs and are summed in a fixed order
+// (deterministic: no float atomics anywhere).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int MODE_GATHER = 0;   // FWD and DGRAD: A = packed weights, B = gathered activations
+constexpr int MODE_WGRAD = 1;    // A = gy, B = gathered activations, reduction over pixels
+
+struct FastDiv {
+    uint32_t mul, shr, one;
+    __host__ void init(uint32_t d) {
+        if (d <= 1) { mul = 0; shr = 0; one = 1; return; }
+        one = 0;
+        int l = 0; while ((1u << l) < d) ++l;           // ceil(log2 d)
+        const int p = 31 + l;
+        mul = (uint32_t)((((uint64_t)1 << p) + d - 1) / d);
+        shr = (uint32_t)(p - 32);
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {  // n < 2^31
+        return one ? n : (__umulhi(n, mul) >> shr);
+    }
+};
+
+struct IgemmParams {
+    const float* A;        // GATHER: packed weights [Kpad][Mpad]; WGRAD: gy [B][M][QH*QW]
+    const float* X;        // gathered tensor
+    float* Out;            // output tensor, or slab base when splits > 1 / WGRAD
+    const float* bias;     // per-m bias (only applied when splits == 1, GATHER mode)
+    const int2* ktab;      // gather table: GATHER -> indexed by k ; WGRAD -> indexed by n
+    int M, Mpad, N, K, Kpad;
+    int XCHW;              // per-sample element stride of the gathered tensor
+    int XW;                // physical row length of the gathered tensor
+    int GH, GW;            // logical gather-space extent (physical << ups)
+    int ups;
+    int SY, SX;            // gather coordinate = q*S + d
+    int QH, QW, QHW;       // pixel grid the GEMM pixel index runs over
+    FastDiv dQHW, dQW;
+    int OCHW, OHW, OW;     // GATHER output tensor geometry
+    int OSY, OSX, OPY, OPX;
+    int ldc;               // WGRAD slab row length
+    int nchunks, chunks_per_split;
+    long long slab_stride; // elements between split slabs
+};
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
+{
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int PAD = (MODE == MODE_WGRAD) ? 2 : 0;
+    constexpr int LDA = BM + PAD, LDB = BN + PAD;
+    constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;
+    constexpr int NTAB = (MODE == MODE_WGRAD) ? 2 * BN : 0;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS) + NTAB];
+    float* const As = smem;
+    float* const Bs = smem + 2 * A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so the
+    // m-tiles that re-read one activation tile are given ids 8 apart -> same L2.
+    const int MT = (p.Mpad + BM - 1) / BM;
+    const int id = blockIdx.x;
+    const int m_tile = (id >> 3) % MT;
+    const int n_tile = ((id >> 3) / MT) * 8 + (id & 7);
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    if (n0 >= p.N) return;                                   // uniform for the whole workgroup
+
+    const int split = blockIdx.y;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(c_begin + p.chunks_per_split, p.nchunks);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---------------- per-thread load state ----------------
+    // GATHER mode: A tile = BK x BM floats of packed weights (float4 copies);
+    //              B tile: thread owns column n_local, rows krow0 + i*KSTEP.
+    constexpr int A_V4 = BK * BM / 4;
+    constexpr int A_PER = (A_V4 + 255) / 256;
+    constexpr int KSTEP = (BN >= 256) ? 1 : 256 / BN;          // BN in {128, 256}
+    constexpr int B_PER = BK / KSTEP;
+    // WGRAD mode: thread owns reduction row k_local = tid % 16; columns (tid/16) + 16*i.
+    constexpr int WA_PER = BM / 16, WB_PER = BN / 16;
+    constexpr int RA = (MODE == MODE_GATHER) ? A_PER * 4 : WA_PER;
+    constexpr int RB = (MODE == MODE_GATHER) ? B_PER : WB_PER;
+    float ra[RA], rb[RB];
+
+    // GATHER-mode column decode (fixed for the whole K loop)
+    int g_ybase = 0, g_xbase = 0, g_off = 0;
+    bool g_valid = false;
+    int g_krow0 = 0;
+    if constexpr (MODE == MODE_GATHER) {
+        const int n_local = tid % BN;
+        g_krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
+        const int n = n0 + n_local;
+        g_valid = n < p.N;
+        const int nn = g_valid ? n : 0;
+        const int b = nn / p.QHW;
+        const int r = nn - b * p.QHW;
+        const int qy = r / p.QW;
+        const int qx = r - qy * p.QW;
+        g_ybase = g_valid ? qy * p.SY : -(1 << 20);             // invalid column never passes the bound test
+        g_xbase = qx * p.SX;
+        g_off = b * p.XCHW;
+    }
+    if constexpr (MODE == MODE_WGRAD) {
+        // stage this tile's n-table (fixed per workgroup) in LDS
+        int2* ntab = reinterpret_cast<int2*>(smem + 2 * (A_ELEMS + B_ELEMS));
+        for (int i = tid; i < BN; i += 256) {
+            const int n = n0 + i;
+            ntab[i] = (n < p.N) ? p.ktab[n] : make_int2(0, (int)0x80008000);   // dy=dx=-32768: always out of range
+        }
+        __syncthreads();
+    }
+
+    auto load_tiles = [&](int chunk) {
+        const int k0 = chunk * BK;
+        if constexpr (MODE == MODE_GATHER) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int idx = tid + i * 256;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < A_V4) {
+                    const int row = idx / (BM / 4);
+                    const int c4 = idx % (BM / 4);
+                    const int m = m0 + c4 * 4;
+                    if (m < p.Mpad) v = *reinterpret_cast<const float4*>(p.A + (size_t)(k0 + row) * p.Mpad + m);
+                }
+                ra[i * 4 + 0] = v.x; ra[i * 4 + 1] = v.y; ra[i * 4 + 2] = v.z; ra[i * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int k = k0 + g_krow0 + i * KSTEP;            // wave-uniform -> scalar table load
+                const int2 e = p.ktab[k];
+                const int iy = g_ybase + (e.y >> 16);
+                const int ix = g_xbase + (int)(short)(e.y & 0xffff);
+                const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+                const int off = g_off + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
+                rb[i] = ok ? p.X[off] : 0.f;
+            }
+        } else {
+            const int k_local = tid & 15;
+            const int c0 = tid >> 4;
+            const int k = k0 + k_local;
+            const bool kv = k < p.K;
+            const uint32_t kk = kv ? (uint32_t)k : 0u;
+            const uint32_t b = p.dQHW.div(kk);
+            const uint32_t r = kk - b * (uint32_t)p.QHW;
+            const uint32_t qy = p.dQW.div(r);
+            const uint32_t qx = r - qy * (uint32_t)p.QW;
+            // A: gy[b][m][r]
+            const float* ap = p.A + (size_t)b * p.M * p.QHW + r;
+#pragma unroll
+            for (int i = 0; i < WA_PER; ++i) {
+                const int m = m0 + c0 + 16 * i;
+                ra[i] = (kv && m < p.M) ? ap[(size_t)m * p.QHW] : 0.f;
+            }
+            const int ybase = kv ? (int)qy * p.SY : -(1 << 20);
+            const int xbase = (int)qx * p.SX;
+            const int xoff = (int)b * p.XCHW;
+            const int2* ntab = reinterpret_cast<const int2*>(smem + 2 * (A_ELEMS + B_ELEMS));
+#pragma unroll
+            for (int i = 0; i < WB_PER; ++i) {
+                const int2 e = ntab[c0 + 16 * i];
+                const int iy = ybase + (e.y >> 16);
+                const int ix = xbase + (int)(short)(e.y & 0xffff);
+                const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+                const int off = xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
+                rb[i] = ok ? p.X[off] : 0.f;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* as = As + buf * A_ELEMS;
+        float* bs = Bs + buf * B_ELEMS;
+        if constexpr (MODE == MODE_GATHER) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int idx = tid + i * 256;
+                if (idx < A_V4) {
+                    const int row = idx / (BM / 4);
+                    const int c4 = idx % (BM / 4);
+                    *reinterpret_cast<float4*>(as + row * LDA + c4 * 4) =
+                        make_float4(ra[i * 4 + 0], ra[i * 4 + 1], ra[i * 4 + 2], ra[i * 4 + 3]);
+                }
+            }
+            const int n_local = tid % BN;
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) bs[(g_krow0 + i * KSTEP) * LDB + n_local] = rb[i];
+        } else {
+            const int k_local = tid & 15;
+            const int c0 = tid >> 4;
+#pragma unroll
+            for (int i = 0; i < WA_PER; ++i) as[k_local * LDA + c0 + 16 * i] = ra[i];
+#pragma unroll
+            for (int i = 0; i < WB_PER; ++i) bs[k_local * LDB + c0 + 16 * i] = rb[i];
+        }
+    };
+
+    // ---------------- main loop: register-staged double buffer, one barrier per k-chunk ----------------
+    if (c_begin < c_end) {
+        load_tiles(c_begin);
+        store_tiles(0);
+        __syncthreads();
+        const int kh = lane >> 5, l31 = lane & 31;
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            const bool more = (c + 1) < c_end;
+            if (more) load_tiles(c + 1);                       // global loads in flight under the MFMAs
+            const float* as = As + buf * A_ELEMS + kh * LDA + wm * (TM * 32) + l31;
+            const float* bs = Bs + buf * B_ELEMS + kh * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = as[ks * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = bs[ks * 2 * LDB + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_tiles(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    // accumulator register r of lane l: column n = l%32, row m = (r&3) + 8*(r>>2) + 4*(l/32)
+    float* out = p.Out + (size_t)split * p.slab_stride;
+    const int l31 = lane & 31, kh = lane >> 5;
+    if constexpr (MODE == MODE_GATHER) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+            if (n >= p.N) continue;
+            const int b = n / p.QHW;
+            const int r = n - b * p.QHW;
+            const int qy = r / p.QW;
+            const int qx = r - qy * p.QW;
+            float* op = out + (size_t)b * p.OCHW + (qy * p.OSY + p.OPY) * p.OW + qx * p.OSX + p.OPX;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                    if (m < p.M) {
+                        float v = acc[i][j][r16];
+                        if (p.bias) v += p.bias[m];
+                        op[(size_t)m * p.OHW] = v;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                    if (m < p.M) out[(size_t)m * p.ldc + n] = acc[i][j][r16];
+                }
+            }
+        }
+    }
+}
+
+// out[i] = sum_s slab[s][i] (+ bias[channel(i)])      -- GATHER-mode split-K combine
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                            const float* __restrict__ bias, int splits,
+                                                            long long slab_stride, int total4, int OHW, int OC)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4* s = reinterpret_cast<const float4*>(slabs) + i;
+    float4 a = s[0];
+    for (int k = 1; k < splits; ++k) {
+        const float4 v = *(reinterpret_cast<const float4*>(slabs + (size_t)k * slab_stride) + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (bias) {
+        const int e = i * 4;
+        // OHW may be < 4 (1x1 outputs): resolve the channel per element
+        a.x += bias[(e / OHW) % OC]; a.y += bias[((e + 1) / OHW) % OC];
+        a.z += bias[((e + 2) / OHW) % OC]; a.w += bias[((e + 3) / OHW) % OC];
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_tail_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                                 const float* __restrict__ bias, int splits,
+                                                                 long long slab_stride, int begin, int total, int OHW, int OC)
+{
+    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float a = slabs[i];
+    for (int k = 1; k < splits; ++k) a += slabs[(size_t)k * slab_stride + i];
+    if (bias) a += bias[(i / OHW) % OC];
+    out[i] = a;
+}
+
+// gw[co][ci][tap] = sum_s slab[s][co][n = tap*Cin + ci]   -- WGRAD combine + re-layout to torch order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
+                                                           int splits, long long slab_stride, int M, int Cin, int T, int ldc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;        // index in torch layout
+    const int CT = Cin * T;
+    if (i >= M * CT) return;
+    const int m = i / CT;
+    const int r = i - m * CT;
+    const int ci = r / T;
+    const int tap = r - ci * T;
+    const size_t src = (size_t)m * ldc + tap * Cin + ci;
+    float a = slabs[src];
+    for (int k = 1; k < splits; ++k) a += slabs[(size_t)k * slab_stride + src];
+    gw[i] = a;
+}
+
+// wp[k][m] = w[wsrc[k] + m*mstride]  (0 where wsrc[k] < 0 or m >= M)
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, const int* __restrict__ wsrc,
+                                                           float* __restrict__ wp, int Kpad_total, int Mpad, int M, int mstride)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Kpad_total * Mpad) return;
+    const int k = i / Mpad, m = i - k * Mpad;
+    const int s = wsrc[k];
+    wp[i] = (s >= 0 && m < M) ? w[(size_t)s + (size_t)m * mstride] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2 };
+
+inline int pick_cfg(int Mpad) {
+    if (Mpad % 128 == 0) return CFG_128x128;
+    if (Mpad % 64 == 0) return CFG_64x256;
+    return CFG_32x256;
+}
+inline void cfg_dims(int cfg, int& bm, int& bn) {
+    if (cfg == CFG_128x128) { bm = 128; bn = 128; }
+    else if (cfg == CFG_64x256) { bm = 64; bn = 256; }
+    else { bm = 32; bn = 256; }
+}
+
+constexpr int TARGET_BLOCKS = 512;     // 2 workgroups per CU
+constexpr int MIN_CHUNKS_PER_SPLIT = 4;
+
+inline void pick_splits(int tiles, int nchunks, int& splits, int& cps) {
+    splits = 1;
+    if (tiles < TARGET_BLOCKS) {
+        splits = (TARGET_BLOCKS + tiles - 1) / tiles;
+        const int maxs = nchunks / MIN_CHUNKS_PER_SPLIT > 0 ? nchunks / MIN_CHUNKS_PER_SPLIT : 1;
+        if (splits > maxs) splits = maxs;
+        if (splits > 256) splits = 256;
+    }
+    cps = (nchunks + splits - 1) / splits;
+    splits = (nchunks + cps - 1) / cps;                   // no empty splits
+    if (splits < 1) splits = 1;
+}
+
+struct Geometry {
+    int Ho, Wo, GHin, GWin, T;
+};
+
+inline int check_desc(const sempyr_conv_desc* d, Geometry& g) {
+    if (!d) SEMPYR_FAIL("conv: null descriptor");
+    if (d->B < 1 || d->Cin < 1 || d->Cout < 1 || d->Hin < 1 || d->Win < 1 || d->kh < 1 || d->kw < 1)
+        SEMPYR_FAIL("conv: non-positive dimension");
+    if (d->stride != 1 && d->stride != 2) SEMPYR_FAIL("conv: stride %d unsupported (1 or 2)", d->stride);
+    if (d->pad < 0 || d->pad > 7) SEMPYR_FAIL("conv: pad %d unsupported", d->pad);
+    if (d->ups != 0 && d->ups != 1) SEMPYR_FAIL("conv: ups must be 0/1");
+    g.GHin = d->Hin << d->ups; g.GWin = d->Win << d->ups;
+    if (g.GHin + 2 * d->pad < d->kh || g.GWin + 2 * d->pad < d->kw) SEMPYR_FAIL("conv: kernel larger than padded input");
+    g.Ho = (g.GHin + 2 * d->pad - d->kh) / d->stride + 1;
+    g.Wo = (g.GWin + 2 * d->pad - d->kw) / d->stride + 1;
+    g.T = d->kh * d->kw;
+    const long long lim = (1ll << 31) - 1;
+    if ((long long)d->B * d->Cin * g.GHin * g.GWin > lim || (long long)d->B * d->Cout * g.Ho * g.Wo > lim ||
+        (long long)d->Cout * d->Cin * g.T > lim)
+        SEMPYR_FAIL("conv: tensor larger than 2^31 elements");
+    return 0;
+}
+
+inline int phase_taps(int kdim, int s, int p, int ph, int& r, int& c) {
+    r = (ph + p) % s; c = (ph + p) / s;
+    return r < kdim ? (kdim - r + s - 1) / s : 0;
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
+    const int MT = (p.Mpad + BM - 1) / BM;
+    const int NT = (p.N + BN - 1) / BN;
+    const int NT8 = (NT + 7) / 8 * 8;
+    dim3 grid(MT * NT8, splits, 1);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(256), 0, st, p);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int MODE>
+int launch_cfg(int cfg, const IgemmParams& p, int splits, hipStream_t st) {
+    switch (cfg) {
+        case CFG_128x128: return launch_igemm<128, 128, 2, 2, MODE>(p, splits, st);
+        case CFG_64x256:  return launch_igemm<64, 256, 1, 4, MODE>(p, splits, st);
+        default:          return launch_igemm<32, 256, 1, 4, MODE>(p, splits, st);
+    }
+}
+
+} // namespace
+
+extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_conv_plan* plan)
+{
+    Geometry g;
+    if (int rc = check_desc(d, g)) return rc;
+    if (!plan) SEMPYR_FAIL("conv plan: null plan");
+    if (mode < 0 || mode > 2) SEMPYR_FAIL("conv plan: bad mode %d", mode);
+    *plan = sempyr_conv_plan{};
+    plan->mode = mode; plan->Ho = g.Ho; plan->Wo = g.Wo;
+    const long long in_numel = (long long)d->B * d->Cin * g.GHin * g.GWin;
+    const long long out_numel = (long long)d->B * d->Cout * g.Ho * g.Wo;
+    int bm, bn;
+    if (mode == SEMPYR_CONV_FWD) {
+        plan->nphases = 1;
+        plan->K[0] = d->Cin * g.T; plan->Kpad[0] = (plan->K[0] + BK - 1) / BK * BK;
+        plan->tab_off[0] = 0; plan->tab_entries = plan->Kpad[0];
+        plan->Mpad = (d->Cout + 31) / 32 * 32;
+        plan->cfg = pick_cfg(plan->Mpad); cfg_dims(plan->cfg, bm, bn);
+        plan->wpack_floats = (long long)plan->Kpad[0] * plan->Mpad;
+        const long long N = (long long)d->B * g.Ho * g.Wo;
+        int cps;
+        pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn), plan->Kpad[0] / BK, plan->splits[0], cps);
+        plan->workspace_bytes = plan->splits[0] > 1 ? (long long)plan->splits[0] * out_numel * 4 : 0;
+    } else if (mode == SEMPYR_CONV_DGRAD) {
+        const int s = d->stride;
+        plan->nphases = s * s;
+        plan->Mpad = (d->Cin + 31) / 32 * 32;
+        plan->cfg = pick_cfg(plan->Mpad); cfg_dims(plan->cfg, bm, bn);
+        int off = 0, max_splits = 1;
+        for (int py = 0; py < s; ++py) for (int px = 0; px < s; ++px) {
+            const int ph = py * s + px;
+            int ry, cy, rx, cx;
+            const int nj = phase_taps(d->kh, s, d->pad, py, ry, cy);
+            const int ni = phase_taps(d->kw, s, d->pad, px, rx, cx);
+            plan->K[ph] = nj * ni * d->Cout;
+            plan->Kpad[ph] = (plan->K[ph] + BK - 1) / BK * BK;
+            plan->tab_off[ph] = off; off += plan->Kpad[ph];
+            const int QH = (g.GHin - py + s - 1) / s, QW = (g.GWin - px + s - 1) / s;
+            const long long N = (long long)d->B * QH * QW;
+            int cps; plan->splits[ph] = 1;
+            if (plan->K[ph] > 0 && N > 0)
+                pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn), plan->Kpad[ph] / BK, plan->splits[ph], cps);
+            if (plan->splits[ph] > max_splits) max_splits = plan->splits[ph];
+        }
+        plan->tab_entries = off;
+        plan->wpack_floats = (long long)off * plan->Mpad;
+        plan->workspace_bytes = max_splits > 1 ? (long long)max_splits * in_numel * 4 : 0;
+    } else {
+        plan->nphases = 1;
+        plan->K[0] = d->B * g.Ho * g.Wo;                        // reduction over pixels
+        plan->Kpad[0] = (plan->K[0] + BK - 1) / BK * BK;
+        const int Nn = (d->Cin * g.T + BK - 1) / BK * BK;       // = FWD Kpad: columns incl. padding
+        plan->tab_off[0] = 0; plan->tab_entries = Nn;
+        plan->Mpad = (d->Cout + 31) / 32 * 32;
+        plan->cfg = pick_cfg(plan->Mpad); cfg_dims(plan->cfg, bm, bn);
+        plan->wpack_floats = 0;
+        int cps;
+        pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(Nn, bn), plan->Kpad[0] / BK, plan->splits[0], cps);
+        plan->workspace_bytes = (long long)plan->splits[0] * d->Cout * Nn * 4;
+    }
+    return 0;
+}
+
+extern "C" int sempyr_conv2d_tables(const sempyr_conv_desc* d, int mode, int32_t* ktab, int32_t* wsrc)
+{
+    Geometry g;
+    if (int rc = check_desc(d, g)) return rc;
+    if (!ktab || !wsrc) SEMPYR_FAIL("conv tables: null output");
+    const int INVALID = (int)0x80008000;                          // dy = dx = -32768
+    const int T = g.T;
+    if (mode == SEMPYR_CONV_FWD || mode == SEMPYR_CONV_WGRAD) {
+        const int K = d->Cin * T, Kpad = (K + BK - 1) / BK * BK;
+        for (int k = 0; k < Kpad; ++k) {
+            if (k < K) {
+                const int tap = k / d->Cin, ci = k % d->Cin;
+                const int ky = tap / d->kw, kx = tap % d->kw;
+                const int dy = ky - d->pad, dx = kx - d->pad;
+                ktab[2 * k] = ci * d->Hin * d->Win;
+                ktab[2 * k + 1] = (int)(((uint32_t)(dy & 0xffff) << 16) | (uint32_t)(dx & 0xffff));
+                wsrc[k] = ci * T + tap;
+            } else { ktab[2 * k] = 0; ktab[2 * k + 1] = INVALID; wsrc[k] = -1; }
+        }
+        return 0;
+    }
+    if (mode != SEMPYR_CONV_DGRAD) SEMPYR_FAIL("conv tables: bad mode %d", mode);
+    const int s = d->stride;
+    int off = 0;
+    for (int py = 0; py < s; ++py) for (int px = 0; px < s; ++px) {
+        int ry, cy, rx, cx;
+        const int nj = phase_taps(d->kh, s, d->pad, py, ry, cy);
+        const int ni = phase_taps(d->kw, s, d->pad, px, rx, cx);
+        const int K = nj * ni * d->Cout, Kpad = (K + BK - 1) / BK * BK;
+        for (int k = 0; k < Kpad; ++k) {
+            const int e = off + k;
+            if (k < K) {
+                const int tp = k / d->Cout, co = k % d->Cout;
+                const int j = tp / ni, i = tp % ni;
+                const int ky = ry + s * j, kx = rx + s * i;
+                const int dy = cy - j, dx = cx - i;
+                ktab[2 * e] = co * g.Ho * g.Wo;
+                ktab[2 * e + 1] = (int)(((uint32_t)(dy & 0xffff) << 16) | (uint32_t)(dx & 0xffff));
+                wsrc[e] = co * d->Cin * T + ky * d->kw + kx;
+            } else { ktab[2 * e] = 0; ktab[2 * e + 1] = INVALID; wsrc[e] = -1; }
+        }
+        off += Kpad;
+    }
+    return 0;
+}
+
+extern "C" int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, const float* w,
+                                          const int32_t* wsrc_dev, float* wpacked, void* stream)
+{
+    sempyr_conv_plan pl;
+    if (int rc = sempyr_conv2d_plan(d, mode, &pl)) return rc;
+    if (mode == SEMPYR_CONV_WGRAD) SEMPYR_FAIL("pack_weights: WGRAD has no packed weights");
+    if (!w || !wsrc_dev || !wpacked) SEMPYR_FAIL("pack_weights: null pointer");
+    const int T = d->kh * d->kw;
+    const int M = mode == SEMPYR_CONV_FWD ? d->Cout : d->Cin;
+    const int mstride = mode == SEMPYR_CONV_FWD ? d->Cin * T : T;
+    const long long total = (long long)pl.tab_entries * pl.Mpad;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, wsrc_dev, wpacked, pl.tab_entries, pl.Mpad, M, mstride);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+static int run_splitk_reduce(const float* slabs, float* out, const float* bias, int splits, long long numel,
+                             int OHW, int OC, hipStream_t st)
+{
+    const int total4 = (int)(numel / 4);
+    if (total4 > 0) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st,
+                           slabs, out, bias, splits, numel, total4, OHW, OC);
+        SEMPYR_CHECK_LAUNCH();
+    }
+    if (numel % 4) {
+        hipLaunchKernelGGL(splitk_reduce_tail_kernel, dim3(1), dim3(256), 0, st,
+                           slabs, out, bias, splits, numel, total4 * 4, (int)numel, OHW, OC);
+        SEMPYR_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
+                                 const int32_t* ktab, const float* bias, float* y,
+                                 void* ws, size_t ws_bytes, void* stream)
+{
+    sempyr_conv_plan pl;
+    if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_FWD, &pl)) return rc;
+    if (!x || !wp || !ktab || !y) SEMPYR_FAIL("conv fwd: null pointer");
+    if ((size_t)pl.workspace_bytes > ws_bytes || (pl.workspace_bytes && !ws))
+        SEMPYR_FAIL("conv fwd: workspace too small (%zu < %lld)", ws_bytes, (long long)pl.workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const long long out_numel = (long long)d->B * d->Cout * pl.Ho * pl.Wo;
+    IgemmParams p{};
+    p.A = wp; p.X = x; p.ktab = reinterpret_cast<const int2*>(ktab);
+    p.M = d->Cout; p.Mpad = pl.Mpad; p.N = d->B * pl.Ho * pl.Wo; p.K = pl.K[0]; p.Kpad = pl.Kpad[0];
+    p.XCHW = d->Cin * d->Hin * d->Win; p.XW = d->Win;
+    p.GH = d->Hin << d->ups; p.GW = d->Win << d->ups; p.ups = d->ups;
+    p.SY = p.SX = d->stride;
+    p.QH = pl.Ho; p.QW = pl.Wo; p.QHW = pl.Ho * pl.Wo; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
+    p.OCHW = d->Cout * pl.Ho * pl.Wo; p.OHW = pl.Ho * pl.Wo; p.OW = pl.Wo;
+    p.OSY = p.OSX = 1; p.OPY = p.OPX = 0;
+    p.nchunks = pl.Kpad[0] / BK;
+    const int splits = pl.splits[0];
+    p.chunks_per_split = ceil_div(p.nchunks, splits);
+    if (splits == 1) { p.Out = y; p.bias = bias; p.slab_stride = 0; }
+    else { p.Out = (float*)ws; p.bias = nullptr; p.slab_stride = out_numel; }
+    if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, st)) return rc;
+    if (splits > 1) return run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, st);
+    return 0;
+}
+
+extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, const float* wp,
+                                   const int32_t* ktab, const float* bias, float* gx,
+                                   void* ws, size_t ws_bytes, void* stream)
+{
+    sempyr_conv_plan pl;
+    if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_DGRAD, &pl)) return rc;
+    if (!gy || !wp || !ktab || !gx) SEMPYR_FAIL("conv dgrad: null pointer");
+    if ((size_t)pl.workspace_bytes > ws_bytes || (pl.workspace_bytes && !ws))
+        SEMPYR_FAIL("conv dgrad: workspace too small (%zu < %lld)", ws_bytes, (long long)pl.workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int s = d->stride;
+    const int GH = d->Hin << d->ups, GW = d->Win << d->ups;
+    const long long in_numel = (long long)d->B * d->Cin * GH * GW;
+    int splits = 1; bool empty_phase = false;
+    for (int ph = 0; ph < pl.nphases; ++ph) {
+        if (pl.splits[ph] > splits) splits = pl.splits[ph];
+        if (pl.K[ph] == 0) empty_phase = true;
+    }
+    float* target = splits > 1 ? (float*)ws : gx;
+    if (empty_phase) {
+        hipError_t e = hipMemsetAsync(target, 0, (size_t)(splits > 1 ? splits : 1) * in_numel * 4, st);
+        if (e != hipSuccess) { sempyr_set_error("conv dgrad: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    for (int py = 0; py < s; ++py) for (int px = 0; px < s; ++px) {
+        const int ph = py * s + px;
+        if (pl.K[ph] == 0) continue;
+        const int QH = (GH - py + s - 1) / s, QW = (GW - px + s - 1) / s;
+        if (QH <= 0 || QW <= 0) continue;
+        IgemmParams p{};
+        p.A = wp + (size_t)pl.tab_off[ph] * pl.Mpad;
+        p.X = gy; p.ktab = reinterpret_cast<const int2*>(ktab) + pl.tab_off[ph];
+        p.M = d->Cin; p.Mpad = pl.Mpad; p.N = d->B * QH * QW; p.K = pl.K[ph]; p.Kpad = pl.Kpad[ph];
+        p.XCHW = d->Cout * pl.Ho * pl.Wo; p.XW = pl.Wo; p.GH = pl.Ho; p.GW = pl.Wo; p.ups = 0;
+        p.SY = p.SX = 1;
+        p.QH = QH; p.QW = QW; p.QHW = QH * QW; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
+        p.OCHW = d->Cin * GH * GW; p.OHW = GH * GW; p.OW = GW;
+        p.OSY = p.OSX = s; p.OPY = py; p.OPX = px;
+        p.nchunks = pl.Kpad[ph] / BK;
+        // all phases share the slab count so one combine pass covers the whole tensor
+        int ph_splits = splits > p.nchunks ? p.nchunks : splits;
+        p.chunks_per_split = ceil_div(p.nchunks, ph_splits);
+        ph_splits = splits;                                         // surplus splits write zeros
+        p.Out = target; p.bias = splits == 1 ? bias : nullptr; p.slab_stride = splits > 1 ? in_numel : 0;
+        if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, ph_splits, st)) return rc;
+    }
+    if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, st);
+    return 0;
+}
+
+extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, const float* x,
+                                   const int32_t* ktab, float* gw,
+                                   void* ws, size_t ws_bytes, void* stream)
+{
+    sempyr_conv_plan pl;
+    if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_WGRAD, &pl)) return rc;
+    if (!gy || !x || !ktab || !gw || !ws) SEMPYR_FAIL("conv wgrad: null pointer");
+    if ((size_t)pl.workspace_bytes > ws_bytes)
+        SEMPYR_FAIL("conv wgrad: workspace too small (%zu < %lld)", ws_bytes, (long long)pl.workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int T = d->kh * d->kw;
+    const int Nn = pl.tab_entries;
+    IgemmParams p{};
+    p.A = gy; p.X = x; p.ktab = reinterpret_cast<const int2*>(ktab);
+    p.M = d->Cout; p.Mpad = pl.Mpad; p.N = Nn; p.K = pl.K[0]; p.Kpad = pl.Kpad[0];
+    p.XCHW = d->Cin * d->Hin * d->Win; p.XW = d->Win;
+    p.GH = d->Hin << d->ups; p.GW = d->Win << d->ups; p.ups = d->ups;
+    p.SY = p.SX = d->stride;
+    p.QH = pl.Ho; p.QW = pl.Wo; p.QHW = pl.Ho * pl.Wo; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
+    p.ldc = Nn;
+    p.nchunks = pl.Kpad[0] / BK;
+    const int splits = pl.splits[0];
+    p.chunks_per_split = ceil_div(p.nchunks, splits);
+    p.Out = (float*)ws; p.slab_stride = (long long)d->Cout * Nn;
+    if (int rc = launch_cfg<MODE_WGRAD>(pl.cfg, p, splits, st)) return rc;
+    const int total = d->Cout * d->Cin * T;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st,
+                       (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,342 @@
+// HBM-bound elementwise kernels of the hot path (coalesced float4 where rows allow it):
+// fused per-row affine + residual + activation (norm apply / eval BatchNorm / residual add,
+// generator.py:27-29,56-57,87 ; discriminator.py:37-39,63-64), activation backward, feature*mask
+// (generator.py:126-129), the WGAN-GP interpolation (train_model.py:51-55), the Normalize maps
+// (train_model.py:240-245), 2x2 pooling / nearest upsample (discriminator.py:57,103 ;
+// generator.py:44) and the ResNet stem max-pool (classifier.py:36).
+#include "common.h"
+
+namespace {
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case SEMPYR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SEMPYR_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case SEMPYR_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+__device__ __forceinline__ float act_deriv_y(float y, int act, float slope) {
+    switch (act) {
+        case SEMPYR_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case SEMPYR_ACT_LRELU: return y > 0.f ? 1.f : slope;
+        case SEMPYR_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+// y = act(x * scale[row] + shift[row] + res)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ res,
+                                                         float* __restrict__ y, long long total, int len, int vec,
+                                                         int act, float slope)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        float sc = 1.f, sh = 0.f;
+        if (scale) { const int row = (int)((i * 4) / len); sc = scale[row]; sh = shift[row]; }
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+        if (res) { const float4 r = reinterpret_cast<const float4*>(res)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
+        v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
+        reinterpret_cast<float4*>(y)[i] = v;
+    } else {
+        if (i >= total) return;
+        float v = x[i];
+        if (scale) { const int row = (int)(i / len); v = v * scale[row] + shift[row]; }
+        if (res) v += res[i];
+        y[i] = act_apply(v, act, slope);
+    }
+}
+
+// g' = gy * act'(y);  gx = g' * scale[row] (scale NULL -> 1);  gres = g' (optional)
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                             const float* __restrict__ scale, float* __restrict__ gx,
+                                                             float* __restrict__ gres, long long total, int len, int vec,
+                                                             int act, float slope)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        float4 g = reinterpret_cast<const float4*>(gy)[i];
+        if (act != SEMPYR_ACT_NONE) {
+            const float4 yv = reinterpret_cast<const float4*>(y)[i];
+            g.x *= act_deriv_y(yv.x, act, slope); g.y *= act_deriv_y(yv.y, act, slope);
+            g.z *= act_deriv_y(yv.z, act, slope); g.w *= act_deriv_y(yv.w, act, slope);
+        }
+        if (gres) reinterpret_cast<float4*>(gres)[i] = g;
+        if (gx) {
+            if (scale) { const float sc = scale[(int)((i * 4) / len)]; g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc; }
+            reinterpret_cast<float4*>(gx)[i] = g;
+        }
+    } else {
+        if (i >= total) return;
+        float g = gy[i];
+        if (act != SEMPYR_ACT_NONE) g *= act_deriv_y(y[i], act, slope);
+        if (gres) gres[i] = g;
+        if (gx) gx[i] = scale ? g * scale[(int)(i / len)] : g;
+    }
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long long total, int vec)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(y)[i] = make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w);
+    } else {
+        if (i >= total) return;
+        y[i] = a[i] * b[i];
+    }
+}
+
+// y = alpha * a + beta * b   (b may be NULL)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    float alpha, float beta, float* __restrict__ y, long long total, int vec)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        float4 u = reinterpret_cast<const float4*>(a)[i];
+        u.x *= alpha; u.y *= alpha; u.z *= alpha; u.w *= alpha;
+        if (b) { const float4 v = reinterpret_cast<const float4*>(b)[i]; u.x += beta * v.x; u.y += beta * v.y; u.z += beta * v.z; u.w += beta * v.w; }
+        reinterpret_cast<float4*>(y)[i] = u;
+    } else {
+        if (i >= total) return;
+        y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+    }
+}
+
+// out = real + alpha[row] * (fake - real)
+__global__ __launch_bounds__(256) void lerp_rows_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                        const float* __restrict__ alpha, float* __restrict__ out,
+                                                        long long total, int len, int vec)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        const float a = alpha[(int)((i * 4) / len)];
+        const float4 r = reinterpret_cast<const float4*>(real)[i], f = reinterpret_cast<const float4*>(fake)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(r.x + a * (f.x - r.x), r.y + a * (f.y - r.y),
+                                                        r.z + a * (f.z - r.z), r.w + a * (f.w - r.w));
+    } else {
+        if (i >= total) return;
+        const float a = alpha[(int)(i / len)];
+        out[i] = real[i] + a * (fake[i] - real[i]);
+    }
+}
+
+// mode 0: y = (x - mean[c]) / std[c]   (true division, as transforms.Normalize's sub_/div_)
+// mode 1: y = x / std[c]                (its backward)
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ stdv, float* __restrict__ y,
+                                                        long long total, int C, int HW, int vec, int mode)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        const int c = (int)(((i * 4) / HW) % C);
+        const float m = mode == 0 ? mean[c] : 0.f, s = stdv[c];
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = (v.x - m) / s; v.y = (v.y - m) / s; v.z = (v.z - m) / s; v.w = (v.w - m) / s;
+        reinterpret_cast<float4*>(y)[i] = v;
+    } else {
+        if (i >= total) return;
+        const int c = (int)((i / HW) % C);
+        y[i] = (x[i] - (mode == 0 ? mean[c] : 0.f)) / stdv[c];
+    }
+}
+
+// y[r][h][w] = scale * sum_{a,b in 0..1} x[r][2h+a][2w+b]      (H, W even; h = H/2)
+__global__ __launch_bounds__(256) void pool2_down_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         long long total_out, int h, int w, float scale)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_out) return;
+    const int ox = (int)(i % w);
+    const long long t = i / w;
+    const int oy = (int)(t % h);
+    const long long r = t / h;
+    const float2* p0 = reinterpret_cast<const float2*>(x + (r * (2 * h) + 2 * oy) * (2 * (long long)w)) + ox;
+    const float2* p1 = p0 + w;
+    const float2 a = *p0, b = *p1;
+    y[i] = scale * ((a.x + a.y) + (b.x + b.y));
+}
+
+// y[r][2h+a][2w+b] = scale * x[r][h][w]
+__global__ __launch_bounds__(256) void pool2_up_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       long long total_in, int h, int w, float scale)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_in) return;
+    const int ix = (int)(i % w);
+    const long long t = i / w;
+    const int iy = (int)(t % h);
+    const long long r = t / h;
+    const float v = scale * x[i];
+    float2* p0 = reinterpret_cast<float2*>(y + (r * (2 * h) + 2 * iy) * (2 * (long long)w)) + ix;
+    *p0 = make_float2(v, v);
+    *(p0 + w) = make_float2(v, v);
+}
+
+// 3x3 stride-2 pad-1 max pool; idx = flat offset (iy*W+ix) of the first maximum in scan order
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int* __restrict__ idx, long long total_out,
+                                                             int H, int W, int Ho, int Wo)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_out) return;
+    const int ox = (int)(i % Wo);
+    const long long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long long r = t / Ho;
+    const float* xr = x + r * H * W;
+    float best = -INFINITY; int bi = -1;
+    for (int a = 0; a < 3; ++a) {
+        const int iy = 2 * oy - 1 + a;
+        if (iy < 0 || iy >= H) continue;
+        for (int b = 0; b < 3; ++b) {
+            const int ix = 2 * ox - 1 + b;
+            if (ix < 0 || ix >= W) continue;
+            const float v = xr[iy * W + ix];
+            if (bi < 0 || v > best || v != v) { best = v; bi = iy * W + ix; }
+        }
+    }
+    y[i] = best; idx[i] = bi;
+}
+
+// gather form of the max-pool backward (deterministic: no atomics)
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ gy, const int* __restrict__ idx,
+                                                             float* __restrict__ gx, long long total_in,
+                                                             int H, int W, int Ho, int Wo)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_in) return;
+    const int ix = (int)(i % W);
+    const long long t = i / W;
+    const int iy = (int)(t % H);
+    const long long r = t / H;
+    const int self = iy * W + ix;
+    const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1;      // windows containing row iy: oy in {iy/2, (iy+1)/2}
+    const int ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
+    float g = 0.f;
+    const float* gr = gy + r * Ho * Wo; const int* ir = idx + r * Ho * Wo;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        if (oy >= Ho) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            if (ox >= Wo) continue;
+            if (ir[oy * Wo + ox] == self) g += gr[oy * Wo + ox];
+        }
+    }
+    gx[i] = g;
+}
+
+} // namespace
+
+#define LAUNCH_1D(kernel, nthreads, st, ...) do { \
+    hipLaunchKernelGGL(kernel, dim3(ceil_div((nthreads), 256)), dim3(256), 0, (st), __VA_ARGS__); \
+    SEMPYR_CHECK_LAUNCH(); } while (0)
+
+extern "C" int sempyr_affine_act(const float* x, const float* scale_row, const float* shift_row, const float* res,
+                                 float* y, int rows, int len, int act, float slope, void* stream)
+{
+    if (!x || !y) SEMPYR_FAIL("affine_act: null pointer");
+    if ((scale_row == nullptr) != (shift_row == nullptr)) SEMPYR_FAIL("affine_act: scale and shift must both be given");
+    if (rows < 1 || len < 1) SEMPYR_FAIL("affine_act: bad dims");
+    if (act < 0 || act > 3) SEMPYR_FAIL("affine_act: bad activation %d", act);
+    const long long total = (long long)rows * len;
+    const int vec = (len % 4 == 0) && aligned16(x) && aligned16(y) && (!res || aligned16(res));
+    LAUNCH_1D(affine_act_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, scale_row, shift_row, res, y, total, len, vec, act, slope);
+    return 0;
+}
+
+extern "C" int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_row, float* gx, float* gres,
+                                     int rows, int len, int act, float slope, void* stream)
+{
+    if (!gy || (!gx && !gres)) SEMPYR_FAIL("affine_act_bwd: null pointer");
+    if (act != SEMPYR_ACT_NONE && !y) SEMPYR_FAIL("affine_act_bwd: activation needs y");
+    if (rows < 1 || len < 1) SEMPYR_FAIL("affine_act_bwd: bad dims");
+    if (act < 0 || act > 3) SEMPYR_FAIL("affine_act_bwd: bad activation %d", act);
+    const long long total = (long long)rows * len;
+    const int vec = (len % 4 == 0) && aligned16(gy) && (!y || aligned16(y)) && (!gx || aligned16(gx)) && (!gres || aligned16(gres));
+    LAUNCH_1D(affine_act_bwd_kernel, vec ? total / 4 : total, (hipStream_t)stream, gy, y, scale_row, gx, gres, total, len, vec, act, slope);
+    return 0;
+}
+
+extern "C" int sempyr_mul(const float* a, const float* b, float* y, int64_t n, void* stream)
+{
+    if (!a || !b || !y || n < 1) SEMPYR_FAIL("mul: bad arguments");
+    const int vec = (n % 4 == 0) && aligned16(a) && aligned16(b) && aligned16(y);
+    LAUNCH_1D(mul_kernel, vec ? n / 4 : n, (hipStream_t)stream, a, b, y, (long long)n, vec);
+    return 0;
+}
+
+extern "C" int sempyr_axpby(const float* a, const float* b, float alpha, float beta, float* y, int64_t n, void* stream)
+{
+    if (!a || !y || n < 1) SEMPYR_FAIL("axpby: bad arguments");
+    const int vec = (n % 4 == 0) && aligned16(a) && (!b || aligned16(b)) && aligned16(y);
+    LAUNCH_1D(axpby_kernel, vec ? n / 4 : n, (hipStream_t)stream, a, b, alpha, beta, y, (long long)n, vec);
+    return 0;
+}
+
+extern "C" int sempyr_lerp_rows(const float* real, const float* fake, const float* alpha_row, float* out,
+                                int rows, int len, void* stream)
+{
+    if (!real || !fake || !alpha_row || !out || rows < 1 || len < 1) SEMPYR_FAIL("lerp_rows: bad arguments");
+    const long long total = (long long)rows * len;
+    const int vec = (len % 4 == 0) && aligned16(real) && aligned16(fake) && aligned16(out);
+    LAUNCH_1D(lerp_rows_kernel, vec ? total / 4 : total, (hipStream_t)stream, real, fake, alpha_row, out, total, len, vec);
+    return 0;
+}
+
+extern "C" int sempyr_normalize(const float* x, const float* mean_c, const float* std_c, float* y,
+                                int N, int C, int HW, int backward, void* stream)
+{
+    if (!x || !std_c || !y || (!backward && !mean_c) || N < 1 || C < 1 || HW < 1) SEMPYR_FAIL("normalize: bad arguments");
+    const long long total = (long long)N * C * HW;
+    const int vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+    LAUNCH_1D(normalize_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, mean_c, std_c, y, total, C, HW, vec, backward ? 1 : 0);
+    return 0;
+}
+
+extern "C" int sempyr_pool2_down(const float* x, float* y, int rows, int H, int W, float scale, void* stream)
+{
+    if (!x || !y || rows < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) SEMPYR_FAIL("pool2_down: bad arguments (H=%d W=%d)", H, W);
+    if (((uintptr_t)x & 7) != 0) SEMPYR_FAIL("pool2_down: input must be 8-byte aligned");
+    const long long total = (long long)rows * (H / 2) * (W / 2);
+    LAUNCH_1D(pool2_down_kernel, total, (hipStream_t)stream, x, y, total, H / 2, W / 2, scale);
+    return 0;
+}
+
+extern "C" int sempyr_pool2_up(const float* x, float* y, int rows, int h, int w, float scale, void* stream)
+{
+    if (!x || !y || rows < 1 || h < 1 || w < 1) SEMPYR_FAIL("pool2_up: bad arguments");
+    if (((uintptr_t)y & 7) != 0) SEMPYR_FAIL("pool2_up: output must be 8-byte aligned");
+    const long long total = (long long)rows * h * w;
+    LAUNCH_1D(pool2_up_kernel, total, (hipStream_t)stream, x, y, total, h, w, scale);
+    return 0;
+}
+
+extern "C" int sempyr_maxpool3s2_fwd(const float* x, float* y, int32_t* idx, int rows, int H, int W, void* stream)
+{
+    if (!x || !y || !idx || rows < 1 || H < 1 || W < 1) SEMPYR_FAIL("maxpool3s2_fwd: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)rows * Ho * Wo;
+    LAUNCH_1D(maxpool3s2_fwd_kernel, total, (hipStream_t)stream, x, y, idx, total, H, W, Ho, Wo);
+    return 0;
+}
+
+extern "C" int sempyr_maxpool3s2_bwd(const float* gy, const int32_t* idx, float* gx, int rows, int H, int W, void* stream)
+{
+    if (!gy || !gx || !idx || rows < 1 || H < 1 || W < 1) SEMPYR_FAIL("maxpool3s2_bwd: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)rows * H * W;
+    LAUNCH_1D(maxpool3s2_bwd_kernel, total, (hipStream_t)stream, gy, idx, gx, total, H, W, Ho, Wo);
+    return 0;
+}

@@ -1,0 +1,493 @@
+// Normalisation kernels: BatchNorm2d (train), InstanceNorm2d(affine), GroupNorm(1, C) —
+// forward, backward and backward-of-backward (the WGAN-GP double backward,
+// train_model.py:69-76 through discriminator.py:16-46).
+//
+// All three norms are one computation over a tensor seen as rows = N*C, len = H*W:
+//   xhat = (x - mean_g) * rstd_g ;  y = act(xhat * gamma_c + beta_c)
+// and differ only in which rows form a statistics group g:
+//   BATCH: rows with equal c   INSTANCE: the row itself   LAYER: rows with equal n
+// So the heavy passes are kind-agnostic, HBM-bound, coalesced float4 row kernels
+// (wavefront shuffle reductions), and the per-kind logic lives in tiny "finalize" kernels that
+// turn per-row sums into per-row affine coefficients.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_deriv(float y, int act, float slope) {
+    // derivative of relu / leaky-relu expressed through the OUTPUT y (sign-preserving activations)
+    if (act == SEMPYR_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == SEMPYR_ACT_LRELU) return y > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+// Reduce NS per-thread sums over the TPR threads that share a row. TPR = 64: one wave per row;
+// TPR = 256: the whole block. Result valid in all participating threads.
+template <int TPR, int NS>
+__device__ __forceinline__ void row_reduce(float (&v)[NS], float* sh) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) v[i] = wave_sum(v[i]);
+    if (TPR == 256) {
+        const int w = threadIdx.x >> 6;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) sh[w * NS + i] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NS; ++i) v[i] = (sh[i] + sh[NS + i]) + (sh[2 * NS + i] + sh[3 * NS + i]);
+    }
+}
+
+// per-row mean and M2 = sum (x - mean)^2 (two passes over the row; the second hits L2)
+template <int TPR>
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ x, int rows, int len, int vec,
+                                                          float* __restrict__ mean_out, float* __restrict__ m2_out)
+{
+    __shared__ float sh[4];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const float* xr = x + (size_t)(live ? row : 0) * len;
+    float s[1] = {0.f};
+    if (live) {
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xr);
+            for (int i = t; i < len / 4; i += TPR) { const float4 v = x4[i]; s[0] += (v.x + v.y) + (v.z + v.w); }
+        } else {
+            for (int i = t; i < len; i += TPR) s[0] += xr[i];
+        }
+    }
+    row_reduce<TPR, 1>(s, sh);
+    const float mean = s[0] / (float)len;
+    float q[1] = {0.f};
+    if (live) {
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xr);
+            for (int i = t; i < len / 4; i += TPR) {
+                const float4 v = x4[i];
+                const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+                q[0] += (a * a + b * b) + (c * c + d * d);
+            }
+        } else {
+            for (int i = t; i < len; i += TPR) { const float a = xr[i] - mean; q[0] += a * a; }
+        }
+    }
+    row_reduce<TPR, 1>(q, sh);
+    if (live && t == 0) { mean_out[row] = mean; m2_out[row] = q[0]; }
+}
+
+__device__ __forceinline__ void group_rows(int kind, int g, int N, int C, int& start, int& stride, int& count) {
+    if (kind == SEMPYR_NORM_BATCH) { start = g; stride = C; count = N; }
+    else if (kind == SEMPYR_NORM_INSTANCE) { start = g; stride = 1; count = 1; }
+    else { start = g * C; stride = 1; count = C; }
+}
+__host__ __device__ __forceinline__ int num_groups(int kind, int N, int C) {
+    return kind == SEMPYR_NORM_BATCH ? C : (kind == SEMPYR_NORM_INSTANCE ? N * C : N);
+}
+
+__global__ void norm_finalize_kernel(int kind, const float* __restrict__ row_mean, const float* __restrict__ row_m2,
+                                     int N, int C, int len, float eps,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* running_mean, float* running_var, long long* nbt, float momentum,
+                                     float* __restrict__ mean_row, float* __restrict__ rstd_row,
+                                     float* __restrict__ scale_row, float* __restrict__ shift_row)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= num_groups(kind, N, C)) return;
+    int start, stride, count;
+    group_rows(kind, g, N, C, start, stride, count);
+    float msum = 0.f;
+    for (int i = 0; i < count; ++i) msum += row_mean[start + i * stride];
+    const float mean = msum / (float)count;
+    float m2 = 0.f;
+    for (int i = 0; i < count; ++i) {
+        const float d = row_mean[start + i * stride] - mean;
+        m2 += row_m2[start + i * stride] + (float)len * d * d;
+    }
+    const float m = (float)count * (float)len;
+    const float var = m2 / m;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int i = 0; i < count; ++i) {
+        const int row = start + i * stride;
+        const int c = row % C;
+        const float sc = rstd * gamma[c];
+        mean_row[row] = mean; rstd_row[row] = rstd;
+        scale_row[row] = sc; shift_row[row] = beta[c] - mean * sc;
+    }
+    if (kind == SEMPYR_NORM_BATCH && running_mean) {
+        const float unbiased = m > 1.f ? m2 / (m - 1.f) : var;
+        running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * mean;
+        running_var[g] = (1.f - momentum) * running_var[g] + momentum * unbiased;
+        if (g == 0 && nbt) *nbt += 1;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      int N, int C, float* __restrict__ scale_row, float* __restrict__ shift_row)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N * C) return;
+    const int c = row % C;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale_row[row] = sc; shift_row[row] = beta[c] - rm[c] * sc;
+}
+
+// s1 = sum gy', s2 = sum gy' * xhat   with gy' = gy * act'(y)
+template <int TPR>
+__global__ __launch_bounds__(256) void norm_bwd_rowsums_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+                                                               int rows, int len, int vec, int act, float slope,
+                                                               float* __restrict__ s1, float* __restrict__ s2)
+{
+    __shared__ float sh[8];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const size_t base = (size_t)(live ? row : 0) * len;
+    const float mean = mean_row[live ? row : 0], rstd = rstd_row[live ? row : 0];
+    float s[2] = {0.f, 0.f};
+    if (live) {
+        if (vec) {
+            const float4* g4 = reinterpret_cast<const float4*>(gy + base);
+            const float4* x4 = reinterpret_cast<const float4*>(x + base);
+            const float4* y4 = reinterpret_cast<const float4*>(y + base);
+            for (int i = t; i < len / 4; i += TPR) {
+                float4 g = g4[i]; const float4 xv = x4[i];
+                if (act != SEMPYR_ACT_NONE) {
+                    const float4 yv = y4[i];
+                    g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
+                    g.z *= act_deriv(yv.z, act, slope); g.w *= act_deriv(yv.w, act, slope);
+                }
+                s[0] += (g.x + g.y) + (g.z + g.w);
+                s[1] += (g.x * (xv.x - mean) + g.y * (xv.y - mean)) + (g.z * (xv.z - mean) + g.w * (xv.w - mean));
+            }
+        } else {
+            for (int i = t; i < len; i += TPR) {
+                float g = gy[base + i];
+                if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[base + i], act, slope);
+                s[0] += g; s[1] += g * (x[base + i] - mean);
+            }
+        }
+    }
+    row_reduce<TPR, 2>(s, sh);
+    if (live && t == 0) { s1[row] = s[0]; s2[row] = s[1] * rstd; }
+}
+
+// group sums -> per-row coefficients of gx = A*gy' + Bc*x + Cc ; channel sums -> ggamma, gbeta
+__global__ void norm_bwd_finalize_kernel(int kind, const float* __restrict__ s1, const float* __restrict__ s2,
+                                         int N, int C, int len, const float* __restrict__ gamma,
+                                         const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+                                         float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
+                                         float* __restrict__ ggamma, float* __restrict__ gbeta)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ng = num_groups(kind, N, C);
+    if (idx < ng) {
+        int start, stride, count;
+        group_rows(kind, idx, N, C, start, stride, count);
+        float SA = 0.f, SB = 0.f;
+        for (int i = 0; i < count; ++i) {
+            const int row = start + i * stride;
+            const float gm = gamma[row % C];
+            SA += gm * s1[row]; SB += gm * s2[row];
+        }
+        const float m = (float)count * (float)len;
+        const float abar = SA / m, s = SB / m;
+        for (int i = 0; i < count; ++i) {
+            const int row = start + i * stride;
+            const float r = rstd_row[row], mean = mean_row[row];
+            cA[row] = r * gamma[row % C];
+            cB[row] = -r * r * s;
+            cC[row] = -r * abar + r * r * s * mean;
+        }
+    } else if (idx < ng + C) {
+        const int c = idx - ng;
+        float a = 0.f, b = 0.f;
+        for (int n = 0; n < N; ++n) { a += s1[n * C + c]; b += s2[n * C + c]; }
+        if (gbeta) gbeta[c] = a;
+        if (ggamma) ggamma[c] = b;
+    }
+}
+
+// gx = cA[row] * gy * act'(y) + cB[row] * x + cC[row]
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ cA, const float* __restrict__ cB,
+                                                             const float* __restrict__ cC,
+                                                             long long total, int len, int vec, int act, float slope,
+                                                             float* __restrict__ gx)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        const int row = (int)((i * 4) / len);
+        const float a = cA[row], b = cB[row], c = cC[row];
+        float4 g = reinterpret_cast<const float4*>(gy)[i];
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        if (act != SEMPYR_ACT_NONE) {
+            const float4 yv = reinterpret_cast<const float4*>(y)[i];
+            g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
+            g.z *= act_deriv(yv.z, act, slope); g.w *= act_deriv(yv.w, act, slope);
+        }
+        float4 o;
+        o.x = a * g.x + b * xv.x + c; o.y = a * g.y + b * xv.y + c;
+        o.z = a * g.z + b * xv.z + c; o.w = a * g.w + b * xv.w + c;
+        reinterpret_cast<float4*>(gx)[i] = o;
+    } else {
+        if (i >= total) return;
+        const int row = (int)(i / len);
+        float g = gy[i];
+        if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[i], act, slope);
+        gx[i] = cA[row] * g + cB[row] * x[i] + cC[row];
+    }
+}
+
+// ---- backward of the backward ----
+// r1 = sum u, r2 = sum u*xhat, r3 = sum gy', r4 = sum gy'*xhat, r5 = sum u*gy'
+template <int TPR>
+__global__ __launch_bounds__(256) void norm_bwdbwd_rowsums_kernel(const float* __restrict__ u, const float* __restrict__ gy,
+                                                                  const float* __restrict__ y, const float* __restrict__ x,
+                                                                  const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+                                                                  int rows, int len, int vec, int act, float slope,
+                                                                  float* __restrict__ sums /* [5][rows] */)
+{
+    __shared__ float sh[20];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const size_t base = (size_t)(live ? row : 0) * len;
+    const float mean = mean_row[live ? row : 0], rstd = rstd_row[live ? row : 0];
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        if (vec) {
+            const float4* u4 = reinterpret_cast<const float4*>(u + base);
+            const float4* g4 = reinterpret_cast<const float4*>(gy + base);
+            const float4* x4 = reinterpret_cast<const float4*>(x + base);
+            const float4* y4 = reinterpret_cast<const float4*>(y + base);
+            for (int i = t; i < len / 4; i += TPR) {
+                const float4 uv = u4[i]; float4 g = g4[i]; float4 xv = x4[i];
+                if (act != SEMPYR_ACT_NONE) {
+                    const float4 yv = y4[i];
+                    g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
+                    g.z *= act_deriv(yv.z, act, slope); g.w *= act_deriv(yv.w, act, slope);
+                }
+                xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
+                s[0] += (uv.x + uv.y) + (uv.z + uv.w);
+                s[1] += (uv.x * xv.x + uv.y * xv.y) + (uv.z * xv.z + uv.w * xv.w);
+                s[2] += (g.x + g.y) + (g.z + g.w);
+                s[3] += (g.x * xv.x + g.y * xv.y) + (g.z * xv.z + g.w * xv.w);
+                s[4] += (uv.x * g.x + uv.y * g.y) + (uv.z * g.z + uv.w * g.w);
+            }
+        } else {
+            for (int i = t; i < len; i += TPR) {
+                const float uv = u[base + i]; float g = gy[base + i]; const float xc = x[base + i] - mean;
+                if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[base + i], act, slope);
+                s[0] += uv; s[1] += uv * xc; s[2] += g; s[3] += g * xc; s[4] += uv * g;
+            }
+        }
+    }
+    row_reduce<TPR, 5>(s, sh);
+    if (live && t == 0) {
+        sums[row] = s[0]; sums[rows + row] = s[1] * rstd; sums[2 * rows + row] = s[2];
+        sums[3 * rows + row] = s[3] * rstd; sums[4 * rows + row] = s[4];
+    }
+}
+
+// coef layout [9][rows]: P1 P2 P3 Q1 Q2 Q3 Q4 ubar t
+__global__ void norm_bwdbwd_finalize_kernel(int kind, const float* __restrict__ sums, int N, int C, int len,
+                                            const float* __restrict__ gamma, const float* __restrict__ mean_row,
+                                            const float* __restrict__ rstd_row, float* __restrict__ coef)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= num_groups(kind, N, C)) return;
+    const int rows = N * C;
+    int start, stride, count;
+    group_rows(kind, g, N, C, start, stride, count);
+    float U = 0.f, T = 0.f, SA = 0.f, SB = 0.f, UA = 0.f;
+    for (int i = 0; i < count; ++i) {
+        const int row = start + i * stride;
+        const float gm = gamma[row % C];
+        U += sums[row]; T += sums[rows + row];
+        SA += gm * sums[2 * rows + row]; SB += gm * sums[3 * rows + row]; UA += gm * sums[4 * rows + row];
+    }
+    const float m = (float)count * (float)len;
+    const float ub = U / m, t = T / m, ab = SA / m, s = SB / m, mua = UA / m;
+    const float w = mua - ub * ab - 3.f * s * t;
+    for (int i = 0; i < count; ++i) {
+        const int row = start + i * stride;
+        const float gm = gamma[row % C];
+        const float r = rstd_row[row], mean = mean_row[row];
+        const float r2 = r * r, r3 = r2 * r;
+        coef[row] = gm * r;                                       // P1
+        coef[rows + row] = -gm * r2 * t;                          // P2
+        coef[2 * rows + row] = -gm * r * ub + gm * r2 * t * mean; // P3
+        coef[3 * rows + row] = -r2 * s;                           // Q1
+        coef[4 * rows + row] = -r2 * t * gm;                      // Q2
+        coef[5 * rows + row] = -r3 * w;                           // Q3
+        coef[6 * rows + row] = r2 * (s * ub + t * ab) + r3 * w * mean; // Q4
+        coef[7 * rows + row] = ub;
+        coef[8 * rows + row] = t;
+    }
+}
+
+__global__ void norm_bwdbwd_ggamma_kernel(const float* __restrict__ sums, const float* __restrict__ coef,
+                                          const float* __restrict__ rstd_row, int N, int C, float* __restrict__ ggamma)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int rows = N * C;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const int row = n * C + c;
+        a += rstd_row[row] * (sums[4 * rows + row] - coef[7 * rows + row] * sums[2 * rows + row]
+                              - coef[8 * rows + row] * sums[3 * rows + row]);
+    }
+    ggamma[c] = a;
+}
+
+// g_gy = act'(y) * (P1*u + P2*x + P3) ;  g_x = Q1*u + Q2*gy*act'(y) + Q3*x + Q4
+__global__ __launch_bounds__(256) void norm_bwdbwd_apply_kernel(const float* __restrict__ u, const float* __restrict__ gy,
+                                                                const float* __restrict__ y, const float* __restrict__ x,
+                                                                const float* __restrict__ coef, int rows,
+                                                                long long total, int len, int vec, int act, float slope,
+                                                                float* __restrict__ g_gy, float* __restrict__ g_x)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= total) return;
+        const int row = (int)((i * 4) / len);
+        const float P1 = coef[row], P2 = coef[rows + row], P3 = coef[2 * rows + row];
+        const float Q1 = coef[3 * rows + row], Q2 = coef[4 * rows + row], Q3 = coef[5 * rows + row], Q4 = coef[6 * rows + row];
+        const float4 uv = reinterpret_cast<const float4*>(u)[i];
+        const float4 gv = reinterpret_cast<const float4*>(gy)[i];
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (act != SEMPYR_ACT_NONE) {
+            const float4 yv = reinterpret_cast<const float4*>(y)[i];
+            d.x = act_deriv(yv.x, act, slope); d.y = act_deriv(yv.y, act, slope);
+            d.z = act_deriv(yv.z, act, slope); d.w = act_deriv(yv.w, act, slope);
+        }
+        float4 a, b;
+        a.x = d.x * (P1 * uv.x + P2 * xv.x + P3); a.y = d.y * (P1 * uv.y + P2 * xv.y + P3);
+        a.z = d.z * (P1 * uv.z + P2 * xv.z + P3); a.w = d.w * (P1 * uv.w + P2 * xv.w + P3);
+        b.x = Q1 * uv.x + Q2 * gv.x * d.x + Q3 * xv.x + Q4; b.y = Q1 * uv.y + Q2 * gv.y * d.y + Q3 * xv.y + Q4;
+        b.z = Q1 * uv.z + Q2 * gv.z * d.z + Q3 * xv.z + Q4; b.w = Q1 * uv.w + Q2 * gv.w * d.w + Q3 * xv.w + Q4;
+        reinterpret_cast<float4*>(g_gy)[i] = a;
+        reinterpret_cast<float4*>(g_x)[i] = b;
+    } else {
+        if (i >= total) return;
+        const int row = (int)(i / len);
+        const float d = act != SEMPYR_ACT_NONE ? act_deriv(y[i], act, slope) : 1.f;
+        g_gy[i] = d * (coef[row] * u[i] + coef[rows + row] * x[i] + coef[2 * rows + row]);
+        g_x[i] = coef[3 * rows + row] * u[i] + coef[4 * rows + row] * gy[i] * d + coef[5 * rows + row] * x[i] + coef[6 * rows + row];
+    }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+inline int check_norm_args(int kind, int N, int C, int HW, int act) {
+    if (kind < 0 || kind > 2) SEMPYR_FAIL("norm: unknown kind %d", kind);
+    if (N < 1 || C < 1 || HW < 1) SEMPYR_FAIL("norm: non-positive dims");
+    if ((long long)N * C * HW >= (1ll << 31)) SEMPYR_FAIL("norm: tensor too large");
+    if (act != SEMPYR_ACT_NONE && act != SEMPYR_ACT_RELU && act != SEMPYR_ACT_LRELU) SEMPYR_FAIL("norm: activation %d not fusable", act);
+    return 0;
+}
+
+} // namespace
+
+extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
+                                 const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                 float* rowbuf, float* scratch, void* stream)
+{
+    if (int rc = check_norm_args(kind, N, C, HW, 0)) return rc;
+    if (!x || !gamma || !beta || !rowbuf || !scratch) SEMPYR_FAIL("norm_stats: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = N * C;
+    const int vec = (HW % 4 == 0) && aligned16(x);
+    float* rmean = scratch; float* rm2 = scratch + rows;
+    if (HW >= 2048) hipLaunchKernelGGL(row_moments_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, HW, vec, rmean, rm2);
+    else hipLaunchKernelGGL(row_moments_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, HW, vec, rmean, rm2);
+    SEMPYR_CHECK_LAUNCH();
+    const int ng = num_groups(kind, N, C);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div(ng, 64)), dim3(64), 0, st, kind, rmean, rm2, N, C, HW, eps,
+                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum,
+                       rowbuf, rowbuf + rows, rowbuf + 2 * rows, rowbuf + 3 * rows);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                     const float* running_var, float eps, int N, int C,
+                                     float* scale_row, float* shift_row, void* stream)
+{
+    if (!gamma || !beta || !running_mean || !running_var || !scale_row || !shift_row) SEMPYR_FAIL("bn_eval_coeffs: null pointer");
+    if (N < 1 || C < 1) SEMPYR_FAIL("bn_eval_coeffs: bad dims");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gamma, beta, running_mean, running_var, eps, N, C, scale_row, shift_row);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const float* x, const float* gamma,
+                               const float* mean_row, const float* rstd_row, int N, int C, int HW,
+                               int act, float slope, float* gx, float* ggamma, float* gbeta,
+                               float* scratch, void* stream)
+{
+    if (int rc = check_norm_args(kind, N, C, HW, act)) return rc;
+    if (!gy || !x || !gamma || !mean_row || !rstd_row || !gx || !scratch) SEMPYR_FAIL("norm_bwd: null pointer");
+    if (act != SEMPYR_ACT_NONE && !y) SEMPYR_FAIL("norm_bwd: activation needs y");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = N * C;
+    const int vec = (HW % 4 == 0) && aligned16(gy) && aligned16(x) && aligned16(gx) && (act == SEMPYR_ACT_NONE || aligned16(y));
+    float* s1 = scratch; float* s2 = scratch + rows;
+    float* cA = scratch + 2 * rows; float* cB = scratch + 3 * rows; float* cC = scratch + 4 * rows;
+    if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, s1, s2);
+    else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, s1, s2);
+    SEMPYR_CHECK_LAUNCH();
+    const int nthreads = num_groups(kind, N, C) + C;
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(nthreads, 64)), dim3(64), 0, st, kind, s1, s2, N, C, HW, gamma,
+                       mean_row, rstd_row, cA, cB, cC, ggamma, gbeta);
+    SEMPYR_CHECK_LAUNCH();
+    const long long total = (long long)rows * HW;
+    const long long nthr = vec ? total / 4 : total;
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, gy, y, x, cA, cB, cC, total, HW, vec, act, slope, gx);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, const float* y, const float* x,
+                                   const float* gamma, const float* mean_row, const float* rstd_row,
+                                   int N, int C, int HW, int act, float slope,
+                                   float* g_gy, float* g_x, float* g_gamma, float* scratch, void* stream)
+{
+    if (int rc = check_norm_args(kind, N, C, HW, act)) return rc;
+    if (!u || !gy || !x || !gamma || !mean_row || !rstd_row || !g_gy || !g_x || !scratch) SEMPYR_FAIL("norm_bwd_bwd: null pointer");
+    if (act != SEMPYR_ACT_NONE && !y) SEMPYR_FAIL("norm_bwd_bwd: activation needs y");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = N * C;
+    const int vec = (HW % 4 == 0) && aligned16(u) && aligned16(gy) && aligned16(x) && aligned16(g_gy) && aligned16(g_x) &&
+                    (act == SEMPYR_ACT_NONE || aligned16(y));
+    float* sums = scratch; float* coef = scratch + 5 * rows;
+    if (HW >= 2048) hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, u, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, sums);
+    else hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, u, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, sums);
+    SEMPYR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(norm_bwdbwd_finalize_kernel, dim3(ceil_div(num_groups(kind, N, C), 64)), dim3(64), 0, st, kind, sums, N, C, HW,
+                       gamma, mean_row, rstd_row, coef);
+    SEMPYR_CHECK_LAUNCH();
+    if (g_gamma) {
+        hipLaunchKernelGGL(norm_bwdbwd_ggamma_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, sums, coef, rstd_row, N, C, g_gamma);
+        SEMPYR_CHECK_LAUNCH();
+    }
+    const long long total = (long long)rows * HW;
+    const long long nthr = vec ? total / 4 : total;
+    hipLaunchKernelGGL(norm_bwdbwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, u, gy, y, x, coef, rows, total, HW, vec, act, slope, g_gy, g_x);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}

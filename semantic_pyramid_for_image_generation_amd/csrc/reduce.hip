@@ -1,0 +1,258 @@
+// Reductions of the loss path (deterministic two-stage sums, wavefront shuffle reductions):
+// WGAN means (train_model.py:39-46), masked L1 feature loss (train_model.py:212-222 with nn.L1Loss,
+// :270), diversity L1s (:109), per-sample L2 norm + (n-1)^2 penalty (:58-66), bias gradients.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PARTS = 1024;
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// stage 1: partial[b] = sum over a grid-stride slice of f(i)
+// OP 0: x ; OP 1: |a*m - b*m| (m optional) ; OP 2: x*x
+template <int OP>
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ m, long long n, int vec,
+                                                          float* __restrict__ partial)
+{
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    if (vec) {
+        const long long n4 = n / 4;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const float4 u = reinterpret_cast<const float4*>(a)[i];
+            if (OP == 0) s += (u.x + u.y) + (u.z + u.w);
+            else if (OP == 2) s += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+            else {
+                const float4 v = reinterpret_cast<const float4*>(b)[i];
+                if (m) {
+                    const float4 k = reinterpret_cast<const float4*>(m)[i];
+                    s += (fabsf(u.x * k.x - v.x * k.x) + fabsf(u.y * k.y - v.y * k.y)) +
+                         (fabsf(u.z * k.z - v.z * k.z) + fabsf(u.w * k.w - v.w * k.w));
+                } else {
+                    s += (fabsf(u.x - v.x) + fabsf(u.y - v.y)) + (fabsf(u.z - v.z) + fabsf(u.w - v.w));
+                }
+            }
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            if (OP == 0) s += a[i];
+            else if (OP == 2) s += a[i] * a[i];
+            else s += m ? fabsf(a[i] * m[i] - b[i] * m[i]) : fabsf(a[i] - b[i]);
+        }
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// stage 2: out = scale * sum partial[0..np)
+__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ partial, int np, float scale,
+                                                        float* __restrict__ out)
+{
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *out = s * scale;
+}
+
+// y[i] = scale * (*g)
+__global__ __launch_bounds__(256) void fill_scalar_kernel(const float* __restrict__ g, float scale, float* __restrict__ y, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = scale * (*g);
+}
+
+// d = sign(a*m - b*m) * m * (*g) * scale ; ga = d ; gb = -d
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ m, const float* __restrict__ g, float scale,
+                                                     float* __restrict__ ga, float* __restrict__ gb, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float k = m ? m[i] : 1.f;
+    const float d = a[i] * k - b[i] * k;
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    const float v = sg * k * (*g) * scale;
+    if (ga) ga[i] = v;
+    if (gb) gb[i] = -v;
+}
+
+// per-row sum of squares -> L2 norm
+template <int TPR>
+__global__ __launch_bounds__(256) void row_l2norm_kernel(const float* __restrict__ x, int rows, int len, int vec,
+                                                         float* __restrict__ norms)
+{
+    __shared__ float sh[4];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const float* xr = x + (size_t)(live ? row : 0) * len;
+    float s = 0.f;
+    if (live) {
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xr);
+            for (int i = t; i < len / 4; i += TPR) { const float4 v = x4[i]; s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+        } else {
+            for (int i = t; i < len; i += TPR) s += xr[i] * xr[i];
+        }
+    }
+    if (TPR == 256) s = block_sum_256(s, sh); else s = wave_sum(s);
+    if (live && t == 0) norms[row] = sqrtf(s);
+}
+
+// gp = mean_r (norm_r - 1)^2
+__global__ __launch_bounds__(256) void gp_final_kernel(const float* __restrict__ norms, int rows, float* __restrict__ gp)
+{
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) { const float d = norms[i] - 1.f; s += d * d; }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *gp = s / (float)rows;
+}
+
+// out = grad * [ (*g) * (2/rows) * (norm_r - 1) / norm_r ]
+__global__ __launch_bounds__(256) void gp_bwd_kernel(const float* __restrict__ grad, const float* __restrict__ norms,
+                                                     const float* __restrict__ g, int rows, long long total, int len, int vec,
+                                                     float* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float gs = (*g) * 2.f / (float)rows;
+    if (vec) {
+        if (i * 4 >= total) return;
+        const float nr = norms[(int)((i * 4) / len)];
+        const float c = nr > 0.f ? gs * (nr - 1.f) / nr : 0.f;
+        float4 v = reinterpret_cast<const float4*>(grad)[i];
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        reinterpret_cast<float4*>(out)[i] = v;
+    } else {
+        if (i >= total) return;
+        const float nr = norms[(int)(i / len)];
+        out[i] = grad[i] * (nr > 0.f ? gs * (nr - 1.f) / nr : 0.f);
+    }
+}
+
+// row sums (for bias gradients): rs[row] = sum x[row][:]
+template <int TPR>
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ x, int rows, int len, int vec, float* __restrict__ rs)
+{
+    __shared__ float sh[4];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const float* xr = x + (size_t)(live ? row : 0) * len;
+    float s = 0.f;
+    if (live) {
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xr);
+            for (int i = t; i < len / 4; i += TPR) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
+        } else {
+            for (int i = t; i < len; i += TPR) s += xr[i];
+        }
+    }
+    if (TPR == 256) s = block_sum_256(s, sh); else s = wave_sum(s);
+    if (live && t == 0) rs[row] = s;
+}
+
+// out[c] = scale * sum_n rs[n*C + c]
+__global__ void channel_fold_kernel(const float* __restrict__ rs, int N, int C, float scale, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += rs[n * C + c];
+    out[c] = a * scale;
+}
+
+template <int OP>
+int two_stage(const float* a, const float* b, const float* m, long long n, float scale, float* out, float* scratch, hipStream_t st)
+{
+    const int vec = (n % 4 == 0) && aligned16(a) && (!b || aligned16(b)) && (!m || aligned16(m));
+    long long work = vec ? n / 4 : n;
+    int blocks = (int)((work + 256 * 8 - 1) / (256 * 8));
+    if (blocks < 1) blocks = 1;
+    if (blocks > MAX_PARTS) blocks = MAX_PARTS;
+    hipLaunchKernelGGL(partial_sum_kernel<OP>, dim3(blocks), dim3(256), 0, st, a, b, m, n, vec, scratch);
+    SEMPYR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, scale, out);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+} // namespace
+
+extern "C" int sempyr_reduce_scratch_floats(void) { return MAX_PARTS; }
+
+extern "C" int sempyr_mean(const float* x, int64_t n, float scale, float* out, float* scratch, void* stream)
+{
+    if (!x || !out || !scratch || n < 1) SEMPYR_FAIL("mean: bad arguments");
+    return two_stage<0>(x, nullptr, nullptr, n, scale / (float)n, out, scratch, (hipStream_t)stream);
+}
+
+extern "C" int sempyr_fill_scalar(const float* g, float scale, float* y, int64_t n, void* stream)
+{
+    if (!g || !y || n < 1) SEMPYR_FAIL("fill_scalar: bad arguments");
+    hipLaunchKernelGGL(fill_scalar_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, g, scale, y, (long long)n);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_l1_mean(const float* a, const float* b, const float* mask, int64_t n, float* out,
+                              float* scratch, void* stream)
+{
+    if (!a || !b || !out || !scratch || n < 1) SEMPYR_FAIL("l1_mean: bad arguments");
+    return two_stage<1>(a, b, mask, n, 1.0f / (float)n, out, scratch, (hipStream_t)stream);
+}
+
+extern "C" int sempyr_l1_mean_bwd(const float* a, const float* b, const float* mask, const float* gout, int64_t n,
+                                  float* ga, float* gb, void* stream)
+{
+    if (!a || !b || !gout || (!ga && !gb) || n < 1) SEMPYR_FAIL("l1_mean_bwd: bad arguments");
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, mask, gout, 1.0f / (float)n, ga, gb, (long long)n);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, void* stream)
+{
+    if (!grad || !norms || !gp || rows < 1 || len < 1) SEMPYR_FAIL("gp_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = (len % 4 == 0) && aligned16(grad);
+    if (len >= 2048) hipLaunchKernelGGL(row_l2norm_kernel<256>, dim3(rows), dim3(256), 0, st, grad, rows, len, vec, norms);
+    else hipLaunchKernelGGL(row_l2norm_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, grad, rows, len, vec, norms);
+    SEMPYR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(256), 0, st, norms, rows, gp);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int rows, int len,
+                             float* out, void* stream)
+{
+    if (!grad || !norms || !gout || !out || rows < 1 || len < 1) SEMPYR_FAIL("gp_bwd: bad arguments");
+    const long long total = (long long)rows * len;
+    const int vec = (len % 4 == 0) && aligned16(grad) && aligned16(out);
+    hipLaunchKernelGGL(gp_bwd_kernel, dim3(ceil_div(vec ? total / 4 : total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad, norms, gout, rows, total, len, vec, out);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, float* scratch, void* stream)
+{
+    if (!x || !out || !scratch || N < 1 || C < 1 || HW < 1) SEMPYR_FAIL("channel_sum: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = N * C;
+    const int vec = (HW % 4 == 0) && aligned16(x);
+    if (HW >= 2048) hipLaunchKernelGGL(row_sum_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, HW, vec, scratch);
+    else hipLaunchKernelGGL(row_sum_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, HW, vec, scratch);
+    SEMPYR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(channel_fold_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, N, C, scale, out);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,795 @@
+"""Differentiable operators of the hot path, each a thin `torch.autograd.Function` over the C ABI.
+
+PyTorch supplies device memory (caching allocator), streams and the autograd *graph*; every
+tensor computation is a hand-written HIP kernel in libsempyr_hip.so.  Each backward is itself
+expressed with differentiable Functions, so the WGAN-GP double backward
+(reference train_model.py:69-76, `create_graph=True`) works through every operator that the
+discriminator uses.  There is no CPU path: non-CUDA(HIP) tensors raise.
+"""
+import ctypes
+import threading
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, CONV_DGRAD, CONV_FWD, CONV_WGRAD, NORM_BATCH,
+                   NORM_INSTANCE, NORM_LAYER, check)
+
+L = _lib.lib
+
+__all__ = ["conv2d", "conv_transpose2d", "norm_act", "bn_eval_act", "act", "add_act", "mul", "normalize",
+           "avg_pool2", "upsample2", "max_pool3s2", "global_avg_pool", "mean", "l1_mean", "gp_loss", "lerp_rows",
+           "input_grads_only", "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_TANH", "NORM_BATCH", "NORM_INSTANCE",
+           "NORM_LAYER"]
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.SempyrError(f"{name}: the sempyr operators run on the GPU only (got a {t.device} tensor); "
+                               "there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise _lib.SempyrError(f"{name}: fp32 expected, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+_REDUCE_SCRATCH = L.sempyr_reduce_scratch_floats()
+
+# When set, parameter (weight / bias / affine) gradients are skipped in backward passes. Used by
+# gradient_penalty (only d pred / d x is wanted, train_model.py:73) — custom Functions cannot see
+# autograd.grad's `inputs=` pruning, so the caller states it.  A plain module global: the autograd
+# engine runs backward on its own device thread.
+_INPUT_GRADS_ONLY = False
+
+
+class input_grads_only:
+    def __enter__(self):
+        global _INPUT_GRADS_ONLY
+        self._prev = _INPUT_GRADS_ONLY
+        _INPUT_GRADS_ONLY = True
+
+    def __exit__(self, *exc):
+        global _INPUT_GRADS_ONLY
+        _INPUT_GRADS_ONLY = self._prev
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution plans
+# ------------------------------------------------------------------------------------------------
+class _ModePlan:
+    __slots__ = ("info", "ktab", "wsrc", "ws_bytes")
+
+
+class ConvPlan:
+    """Geometry + device tables of one Conv2d shape (cached per shape and device)."""
+
+    def __init__(self, key, device):
+        B, Cin, Hin, Win, Cout, kh, kw, stride, pad, ups = key
+        self.key = key
+        self.device = device
+        self.desc = _lib.ConvDesc(B, Cin, Hin, Win, Cout, kh, kw, stride, pad, ups)
+        self.desc_ref = ctypes.byref(self.desc)
+        self.modes = {}
+        info = self.mode(CONV_FWD).info
+        self.Ho, self.Wo = info.Ho, info.Wo
+        self.B, self.Cin, self.Hin, self.Win, self.Cout = B, Cin, Hin, Win, Cout
+        self.kh, self.kw, self.stride, self.pad, self.ups = kh, kw, stride, pad, ups
+        self._noups = None
+
+    def mode(self, mode):
+        mp = self.modes.get(mode)
+        if mp is None:
+            mp = _ModePlan()
+            mp.info = _lib.ConvPlanInfo()
+            check(L.sempyr_conv2d_plan(self.desc_ref, mode, ctypes.byref(mp.info)), "sempyr_conv2d_plan")
+            n = mp.info.tab_entries
+            tab_mode = CONV_FWD if mode == CONV_WGRAD else mode
+            kt = torch.empty(max(2 * n, 2), dtype=torch.int32)
+            ws = torch.empty(max(n, 1), dtype=torch.int32)
+            check(L.sempyr_conv2d_tables(self.desc_ref, tab_mode, kt.data_ptr(), ws.data_ptr()), "sempyr_conv2d_tables")
+            mp.ktab = kt.to(self.device)
+            mp.wsrc = ws.to(self.device)
+            mp.ws_bytes = int(mp.info.workspace_bytes)
+            self.modes[mode] = mp
+        return mp
+
+    def noups(self):
+        """The same convolution seen on the already-upsampled input (for the input gradient)."""
+        if not self.ups:
+            return self
+        if self._noups is None:
+            B, Cin, Hin, Win, Cout, kh, kw, stride, pad, _ = self.key
+            self._noups = get_plan((B, Cin, Hin * 2, Win * 2, Cout, kh, kw, stride, pad, 0), self.device)
+        return self._noups
+
+
+_PLANS = {}
+_PLANS_LOCK = threading.Lock()
+
+
+def get_plan(key, device):
+    k = (key, device.index)
+    p = _PLANS.get(k)
+    if p is None:
+        with _PLANS_LOCK:
+            p = _PLANS.get(k)
+            if p is None:
+                p = ConvPlan(key, device)
+                _PLANS[k] = p
+    return p
+
+
+def _packed_weights(plan, w, mode):
+    """k-major re-layout of a weight tensor; cached on leaf tensors (parameters) per version."""
+    mp = plan.mode(mode)
+    wkey = (mode, plan.key[1:])          # layout does not depend on the batch size
+    cache = None
+    if w.is_leaf:
+        cache = getattr(w, "_sempyr_pack", None)
+        if cache is None:
+            cache = {}
+            try:
+                w._sempyr_pack = cache
+            except Exception:  # pragma: no cover - tensors always accept attributes
+                cache = None
+        if cache is not None:
+            hit = cache.get(wkey)
+            if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
+                return hit[1]
+    wp = torch.empty(max(int(mp.info.wpack_floats), 1), dtype=torch.float32, device=w.device)
+    check(L.sempyr_conv2d_pack_weights(plan.desc_ref, mode, w.data_ptr(), mp.wsrc.data_ptr(), wp.data_ptr(), _stream()),
+          "sempyr_conv2d_pack_weights")
+    if cache is not None:
+        cache[wkey] = (w._version, wp, w.data_ptr())
+    return wp
+
+
+def _workspace(nbytes, device):
+    if nbytes <= 0:
+        return None
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def _raw_conv_fwd(plan, x, w, bias):
+    mp = plan.mode(CONV_FWD)
+    wp = _packed_weights(plan, w, CONV_FWD)
+    y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device)
+    ws = _workspace(mp.ws_bytes, x.device)
+    check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(), _p(bias), y.data_ptr(),
+                              _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
+    return y
+
+
+def _raw_conv_dgrad(plan, gy, w, bias):
+    """plan.ups must be 0 here (callers pass plan.noups())."""
+    mp = plan.mode(CONV_DGRAD)
+    wp = _packed_weights(plan, w, CONV_DGRAD)
+    gx = torch.empty((plan.B, plan.Cin, plan.Hin, plan.Win), dtype=torch.float32, device=gy.device)
+    ws = _workspace(mp.ws_bytes, gy.device)
+    check(L.sempyr_conv2d_dgrad(plan.desc_ref, gy.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(), _p(bias), gx.data_ptr(),
+                                _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_dgrad")
+    return gx
+
+
+def _raw_conv_wgrad(plan, gy, x):
+    mp = plan.mode(CONV_WGRAD)
+    gw = torch.empty((plan.Cout, plan.Cin, plan.kh, plan.kw), dtype=torch.float32, device=gy.device)
+    ws = _workspace(mp.ws_bytes, gy.device)
+    check(L.sempyr_conv2d_wgrad(plan.desc_ref, gy.data_ptr(), x.data_ptr(), mp.ktab.data_ptr(), gw.data_ptr(),
+                                _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_wgrad")
+    return gw
+
+
+def _channel_sum_raw(g, scale=1.0):
+    N, C = g.shape[0], g.shape[1]
+    HW = g.numel() // (N * C)
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    scratch = torch.empty(N * C, dtype=torch.float32, device=g.device)
+    check(L.sempyr_channel_sum(g.data_ptr(), N, C, HW, scale, out.data_ptr(), scratch.data_ptr(), _stream()),
+          "sempyr_channel_sum")
+    return out
+
+
+def _bias_grad(g):
+    if torch.is_grad_enabled() and g.requires_grad:
+        raise NotImplementedError("double backward through a bias gradient is not part of the hot path")
+    return _channel_sum_raw(g)
+
+
+class _ConvFwd(Function):
+    """y = conv2d(x[, upsampled x2], w) + bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, plan):
+        x = _req(x, "conv input"); w = _req(w, "conv weight")
+        if bias is not None:
+            bias = _req(bias, "conv bias")
+        ctx.save_for_backward(x, w)
+        ctx.plan = plan
+        ctx.has_bias = bias is not None
+        return _raw_conv_fwd(plan, x, w, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        plan = ctx.plan
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_input_grad(gy, w, plan)
+        if not _INPUT_GRADS_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = _ConvWgrad.apply(gy, x, plan)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = _bias_grad(gy)
+        return gx, gw, gb, None
+
+
+def _conv_input_grad(gy, w, plan):
+    gx = _ConvDgrad.apply(gy, w, None, plan.noups())
+    if plan.ups:
+        gx = _Pool2Down.apply(gx, 1.0)
+    return gx
+
+
+class _ConvDgrad(Function):
+    """gx = conv_transpose2d(gy, w) (+ bias): the input gradient of `plan`'s conv, and the forward of a
+    ConvTranspose2d.  plan.ups == 0."""
+
+    @staticmethod
+    def forward(ctx, gy, w, bias, plan):
+        gy = _req(gy, "dgrad input"); w = _req(w, "conv weight")
+        if bias is not None:
+            bias = _req(bias, "bias")
+        ctx.save_for_backward(gy, w)
+        ctx.plan = plan
+        ctx.has_bias = bias is not None
+        return _raw_conv_dgrad(plan, gy, w, bias)
+
+    @staticmethod
+    def backward(ctx, u):
+        gy, w = ctx.saved_tensors
+        plan = ctx.plan
+        u = u.contiguous()
+        g_gy = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_gy = _ConvFwd.apply(u, w, None, plan)
+        if not _INPUT_GRADS_ONLY:
+            if ctx.needs_input_grad[1]:
+                g_w = _ConvWgrad.apply(gy, u, plan)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                g_b = _bias_grad(u)
+        return g_gy, g_w, g_b, None
+
+
+class _ConvWgrad(Function):
+    """gw = sum_{b,pix} gy (x) x  — weight gradient of `plan`'s conv (x may be pre-upsample)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, plan):
+        gy = _req(gy, "wgrad gy"); x = _req(x, "wgrad x")
+        ctx.save_for_backward(gy, x)
+        ctx.plan = plan
+        return _raw_conv_wgrad(plan, gy, x)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        plan = ctx.plan
+        ggw = ggw.contiguous()
+        g_gy = g_x = None
+        if ctx.needs_input_grad[0]:
+            g_gy = _ConvFwd.apply(x, ggw, None, plan)
+        if ctx.needs_input_grad[1]:
+            g_x = _conv_input_grad(gy, ggw, plan)
+        return g_gy, g_x, None
+
+
+def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False):
+    """nn.Conv2d forward (reference generator.py:25, discriminator.py:37), optionally reading its input
+    through a fused nn.UpsamplingNearest2d(2) (generator.py:44,78)."""
+    B, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = w.shape
+    if Cin_w != Cin:
+        raise _lib.SempyrError(f"conv2d: weight expects {Cin_w} input channels, got {Cin}")
+    plan = get_plan((B, Cin, H, W, Cout, kh, kw, stride, padding, 1 if upsample else 0), x.device)
+    return _ConvFwd.apply(x, w, bias, plan)
+
+
+def conv_transpose2d(x, w, bias=None, stride=1, padding=0):
+    """nn.ConvTranspose2d forward (reference generator.py:23,115): the input gradient of the Conv2d
+    (Cout_t -> Cin_t) that shares the weight tensor (Cin_t, Cout_t, kh, kw)."""
+    B, Cin_t, H, W = x.shape
+    Cin_w, Cout_t, kh, kw = w.shape
+    if Cin_w != Cin_t:
+        raise _lib.SempyrError(f"conv_transpose2d: weight expects {Cin_w} input channels, got {Cin_t}")
+    Ho = (H - 1) * stride - 2 * padding + kh
+    Wo = (W - 1) * stride - 2 * padding + kw
+    plan = get_plan((B, Cout_t, Ho, Wo, Cin_t, kh, kw, stride, padding, 0), x.device)
+    if plan.Ho != H or plan.Wo != W:
+        raise _lib.SempyrError("conv_transpose2d: inconsistent geometry")
+    return _ConvDgrad.apply(x, w, bias, plan)
+
+
+def linear(x, w, bias=None):
+    """nn.Linear (ResNet18 fc, classifier.py:43) as a 1x1 convolution on a 1x1 image."""
+    B, F = x.shape
+    y = conv2d(x.reshape(B, F, 1, 1), w.reshape(w.shape[0], F, 1, 1), bias)
+    return y.reshape(B, w.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation (+ fused activation)
+# ------------------------------------------------------------------------------------------------
+def _nchw(x):
+    N, C = x.shape[0], x.shape[1]
+    return N, C, x.numel() // (N * C)
+
+
+class _NormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, kind, act_kind, slope, eps, bn_state):
+        x = _req(x, "norm input"); gamma = _req(gamma, "norm weight"); beta = _req(beta, "norm bias")
+        N, C, HW = _nchw(x)
+        rows = N * C
+        rowbuf = torch.empty(4 * rows, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
+        rm = rv = nbt = None
+        momentum = 0.0
+        if bn_state is not None:
+            rm, rv, nbt, momentum = bn_state
+        check(L.sempyr_norm_stats(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(),
+                                  _p(rm), _p(rv), _p(nbt), momentum, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
+              "sempyr_norm_stats")
+        y = torch.empty_like(x)
+        check(L.sempyr_affine_act(x.data_ptr(), rowbuf.data_ptr() + 8 * rows, rowbuf.data_ptr() + 12 * rows, 0,
+                                  y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
+        ctx.save_for_backward(x, y if act_kind != ACT_NONE else None, gamma, rowbuf)
+        ctx.cfg = (kind, act_kind, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, rowbuf = ctx.saved_tensors
+        kind, act_kind, slope = ctx.cfg
+        gx, gg, gb = _NormActBwd.apply(gy.contiguous(), x, y, gamma, rowbuf, kind, act_kind, slope)
+        if _INPUT_GRADS_ONLY:
+            gg = gb = None
+        return gx, gg, gb, None, None, None, None, None
+
+
+class _NormActBwd(Function):
+    """(gx, ggamma, gbeta) of y = act(norm(x)); differentiable w.r.t. gy, x, gamma through gx."""
+
+    @staticmethod
+    def forward(ctx, gy, x, y, gamma, rowbuf, kind, act_kind, slope):
+        gy = _req(gy, "norm grad")
+        N, C, HW = _nchw(x)
+        rows = N * C
+        gx = torch.empty_like(x)
+        want_param = not _INPUT_GRADS_ONLY
+        gg = torch.empty(C, dtype=torch.float32, device=x.device) if want_param else None
+        gb = torch.empty(C, dtype=torch.float32, device=x.device) if want_param else None
+        scratch = torch.empty(5 * rows, dtype=torch.float32, device=x.device)
+        check(L.sempyr_norm_bwd(kind, gy.data_ptr(), _p(y), x.data_ptr(), gamma.data_ptr(), rowbuf.data_ptr(),
+                                rowbuf.data_ptr() + 4 * rows, N, C, HW, act_kind, slope, gx.data_ptr(), _p(gg), _p(gb),
+                                scratch.data_ptr(), _stream()), "sempyr_norm_bwd")
+        ctx.save_for_backward(gy, x, y, gamma, rowbuf)
+        ctx.cfg = (kind, act_kind, slope)
+        ctx.set_materialize_grads(False)
+        if not want_param:
+            gg = torch.zeros(0, device=x.device)
+            gb = torch.zeros(0, device=x.device)
+            ctx.mark_non_differentiable(gg, gb)
+        return gx, gg, gb
+
+    @staticmethod
+    def backward(ctx, u, ugg, ugb):
+        if ugg is not None or ugb is not None:
+            raise NotImplementedError("second-order terms through the affine-parameter gradients of a norm layer "
+                                      "are not part of the hot path (WGAN-GP differentiates d pred / d x only)")
+        gy, x, y, gamma, rowbuf = ctx.saved_tensors
+        kind, act_kind, slope = ctx.cfg
+        if u is None:
+            return None, None, None, None, None, None, None, None
+        u = _req(u, "norm double-backward grad")
+        N, C, HW = _nchw(x)
+        rows = N * C
+        g_gy = torch.empty_like(x)
+        g_x = torch.empty_like(x)
+        want_param = ctx.needs_input_grad[3] and not _INPUT_GRADS_ONLY
+        g_gamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param else None
+        scratch = torch.empty(14 * rows, dtype=torch.float32, device=x.device)
+        check(L.sempyr_norm_bwd_bwd(kind, u.data_ptr(), gy.data_ptr(), _p(y), x.data_ptr(), gamma.data_ptr(),
+                                    rowbuf.data_ptr(), rowbuf.data_ptr() + 4 * rows, N, C, HW, act_kind, slope,
+                                    g_gy.data_ptr(), g_x.data_ptr(), _p(g_gamma), scratch.data_ptr(), _stream()),
+              "sempyr_norm_bwd_bwd")
+        return g_gy, g_x, None, g_gamma, None, None, None, None
+
+
+def norm_act(x, gamma, beta, kind, act_kind=ACT_NONE, slope=0.0, eps=1e-5, bn_state=None):
+    """Training-mode BatchNorm2d / InstanceNorm2d(affine) / GroupNorm(1,C) fused with ReLU or
+    LeakyReLU (reference generator.py:27-29, discriminator.py:37-39).  `bn_state` =
+    (running_mean, running_var, num_batches_tracked, momentum) is updated in place for BATCH."""
+    return _NormAct.apply(x, gamma, beta, kind, act_kind, slope, eps, bn_state)
+
+
+class _AffineRowAct(Function):
+    """y = act(x*scale_row + shift_row [+ res]) with constant (non-differentiable) coefficients."""
+
+    @staticmethod
+    def forward(ctx, x, res, coeffs, act_kind, slope):
+        x = _req(x, "input")
+        if res is not None:
+            res = _req(res, "residual")
+        N, C, HW = _nchw(x)
+        rows = N * C
+        y = torch.empty_like(x)
+        check(L.sempyr_affine_act(x.data_ptr(), coeffs.data_ptr(), coeffs.data_ptr() + 4 * rows, _p(res), y.data_ptr(),
+                                  rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
+        ctx.save_for_backward(y if act_kind != ACT_NONE else None, coeffs)
+        ctx.cfg = (act_kind, slope, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, coeffs = ctx.saved_tensors
+        act_kind, slope, has_res = ctx.cfg
+        if torch.is_grad_enabled() and gy.requires_grad:
+            raise NotImplementedError("double backward through eval-mode BatchNorm is not part of the hot path")
+        gy = _req(gy, "grad")
+        N, C, HW = _nchw(gy)
+        rows = N * C
+        gx = torch.empty_like(gy) if ctx.needs_input_grad[0] else None
+        gres = torch.empty_like(gy) if (has_res and ctx.needs_input_grad[1]) else None
+        if gx is None and gres is None:
+            return None, None, None, None, None
+        check(L.sempyr_affine_act_bwd(gy.data_ptr(), _p(y), coeffs.data_ptr(), _p(gx), _p(gres), rows, HW, act_kind, slope,
+                                      _stream()), "sempyr_affine_act_bwd")
+        return gx, gres, None, None, None
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, N):
+    C = gamma.numel()
+    coeffs = torch.empty(2 * N * C, dtype=torch.float32, device=gamma.device)
+    check(L.sempyr_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), eps,
+                                  N, C, coeffs.data_ptr(), coeffs.data_ptr() + 4 * N * C, _stream()), "sempyr_bn_eval_coeffs")
+    return coeffs
+
+
+def bn_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, res=None, act_kind=ACT_NONE, slope=0.0):
+    """Eval-mode BatchNorm2d (+ residual add + activation) with frozen statistics and parameters
+    (ResNet18 classifier, classifier.py:34 under .eval(); generator under `sample`, train_model.py:153)."""
+    coeffs = bn_eval_coeffs(_req(gamma), _req(beta), _req(running_mean), _req(running_var), eps, x.shape[0])
+    return _AffineRowAct.apply(x, res, coeffs, act_kind, slope)
+
+
+# ------------------------------------------------------------------------------------------------
+# activations / residual add
+# ------------------------------------------------------------------------------------------------
+def _act_raw(x, res, act_kind, slope):
+    y = torch.empty_like(x)
+    check(L.sempyr_affine_act(x.data_ptr(), 0, 0, _p(res), y.data_ptr(), 1, x.numel(), act_kind, slope, _stream()),
+          "sempyr_affine_act")
+    return y
+
+
+class _AddAct(Function):
+    """y = act(a [+ b])"""
+
+    @staticmethod
+    def forward(ctx, a, b, act_kind, slope):
+        a = _req(a, "input")
+        if b is not None:
+            b = _req(b, "input")
+            if b.shape != a.shape:
+                raise _lib.SempyrError("add_act: shape mismatch")
+        y = _act_raw(a, b, act_kind, slope)
+        ctx.save_for_backward(y if act_kind != ACT_NONE else None)
+        ctx.cfg = (act_kind, slope, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        act_kind, slope, has_b = ctx.cfg
+        g = gy if act_kind == ACT_NONE else _ActBwd.apply(gy, y, act_kind, slope)
+        return g, (g if has_b else None), None, None
+
+
+class _ActBwd(Function):
+    """g = gy * act'(y) (linear in gy)."""
+
+    @staticmethod
+    def forward(ctx, gy, y, act_kind, slope):
+        gy = _req(gy, "grad")
+        g = torch.empty_like(gy)
+        check(L.sempyr_affine_act_bwd(gy.data_ptr(), y.data_ptr(), 0, g.data_ptr(), 0, 1, gy.numel(), act_kind, slope,
+                                      _stream()), "sempyr_affine_act_bwd")
+        ctx.save_for_backward(y)
+        ctx.cfg = (act_kind, slope)
+        return g
+
+    @staticmethod
+    def backward(ctx, u):
+        (y,) = ctx.saved_tensors
+        act_kind, slope = ctx.cfg
+        if act_kind == ACT_TANH:
+            raise NotImplementedError("double backward through tanh is not part of the hot path")
+        return _ActBwd.apply(u.contiguous(), y, act_kind, slope), None, None, None
+
+
+def act(x, act_kind, slope=0.0):
+    """nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh (generator.py:48,120 ; discriminator.py:99,102)."""
+    return _AddAct.apply(x, None, act_kind, slope)
+
+
+def add_act(a, b, act_kind=ACT_NONE, slope=0.0):
+    """`x += residual; x = activation(x)` (generator.py:56-57, discriminator.py:63-64) and gen + features
+    (generator.py:87)."""
+    return _AddAct.apply(a, b, act_kind, slope)
+
+
+class _Mul(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _req(a, "input"); b = _req(b, "input")
+        if a.shape != b.shape:
+            raise _lib.SempyrError("mul: shape mismatch")
+        ctx.save_for_backward(a, b)
+        y = torch.empty_like(a)
+        check(L.sempyr_mul(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "sempyr_mul")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = _Mul.apply(g.contiguous(), b) if ctx.needs_input_grad[0] else None
+        gb = _Mul.apply(g.contiguous(), a) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def mul(a, b):
+    """features[i] * masks[i] (generator.py:126-129)."""
+    return _Mul.apply(a, b)
+
+
+class _Normalize(Function):
+    @staticmethod
+    def forward(ctx, x, mean_c, std_c, backward_mode):
+        x = _req(x, "input")
+        N, C, HW = _nchw(x)
+        y = torch.empty_like(x)
+        check(L.sempyr_normalize(x.data_ptr(), _p(mean_c), std_c.data_ptr(), y.data_ptr(), N, C, HW,
+                                 1 if backward_mode else 0, _stream()), "sempyr_normalize")
+        ctx.save_for_backward(mean_c, std_c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        mean_c, std_c = ctx.saved_tensors
+        return _Normalize.apply(g.contiguous(), mean_c, std_c, True), None, None, None
+
+
+def normalize(x, mean_c, std_c):
+    """transforms.Normalize(mean, std) on a batch (train_model.py:240-245,308-309,98)."""
+    return _Normalize.apply(x, mean_c, std_c, False)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / upsampling
+# ------------------------------------------------------------------------------------------------
+class _Pool2Down(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _req(x, "input")
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(L.sempyr_pool2_down(x.data_ptr(), y.data_ptr(), N * C, H, W, scale, _stream()), "sempyr_pool2_down")
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Pool2Up.apply(g.contiguous(), ctx.scale), None
+
+
+class _Pool2Up(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _req(x, "input")
+        N, C, h, w = x.shape
+        y = torch.empty((N, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        check(L.sempyr_pool2_up(x.data_ptr(), y.data_ptr(), N * C, h, w, scale, _stream()), "sempyr_pool2_up")
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Pool2Down.apply(g.contiguous(), ctx.scale), None
+
+
+def avg_pool2(x):
+    """nn.AvgPool2d(2) (discriminator.py:57,103)."""
+    return _Pool2Down.apply(x, 0.25)
+
+
+def upsample2(x):
+    """nn.UpsamplingNearest2d(scale_factor=2) as a standalone op (normally fused into conv2d)."""
+    return _Pool2Up.apply(x, 1.0)
+
+
+class _MaxPool3s2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "input")
+        N, C, H, W = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, C, Ho, Wo), dtype=torch.int32, device=x.device)
+        check(L.sempyr_maxpool3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N * C, H, W, _stream()),
+              "sempyr_maxpool3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.in_shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled() and g.requires_grad:
+            raise NotImplementedError("double backward through max-pool is not part of the hot path")
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.in_shape
+        g = _req(g, "grad")
+        gx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        check(L.sempyr_maxpool3s2_bwd(g.data_ptr(), idx.data_ptr(), gx.data_ptr(), N * C, H, W, _stream()),
+              "sempyr_maxpool3s2_bwd")
+        return gx
+
+
+def max_pool3s2(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet18 stem (classifier.py:36)."""
+    return _MaxPool3s2.apply(x)
+
+
+def global_avg_pool(x):
+    """nn.AdaptiveAvgPool2d((1,1)) (classifier.py:41).  Forward only: tap 5 never enters a loss
+    (train_model.py:212-222 uses taps 1..4)."""
+    x = _req(x.detach(), "input")
+    N, C, HW = _nchw(x)
+    out = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    # channel_sum over a (1, N*C, HW) view = per-row sums
+    check(L.sempyr_channel_sum(x.data_ptr(), 1, N * C, HW, 1.0 / HW, out.data_ptr(), scratch.data_ptr(), _stream()),
+          "sempyr_channel_sum")
+    return out.view(N, C, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss-path reductions
+# ------------------------------------------------------------------------------------------------
+class _Mean(Function):
+    """scale * mean(x) -> 0-d tensor."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _req(x, "input")
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(_REDUCE_SCRATCH, dtype=torch.float32, device=x.device)
+        check(L.sempyr_mean(x.data_ptr(), x.numel(), scale, out.data_ptr(), scratch.data_ptr(), _stream()), "sempyr_mean")
+        ctx.shape = x.shape
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled() and g.requires_grad:
+            raise NotImplementedError("double backward through a mean is not part of the hot path")
+        g = _req(g, "grad")
+        n = 1
+        for s in ctx.shape:
+            n *= s
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(L.sempyr_fill_scalar(g.data_ptr(), ctx.scale / n, gx.data_ptr(), n, _stream()), "sempyr_fill_scalar")
+        return gx, None
+
+
+def mean(x, scale=1.0):
+    """`x.mean()` / `-x.mean()` of the WGAN losses (train_model.py:39-46)."""
+    return _Mean.apply(x, scale)
+
+
+class _L1Mean(Function):
+    """mean |a*m - b*m| (m optional)."""
+
+    @staticmethod
+    def forward(ctx, a, b, m):
+        a = _req(a, "input"); b = _req(b, "input")
+        if a.shape != b.shape or (m is not None and m.shape != a.shape):
+            raise _lib.SempyrError("l1_mean: shape mismatch")
+        if m is not None:
+            m = _req(m, "mask")
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        scratch = torch.empty(_REDUCE_SCRATCH, dtype=torch.float32, device=a.device)
+        check(L.sempyr_l1_mean(a.data_ptr(), b.data_ptr(), _p(m), a.numel(), out.data_ptr(), scratch.data_ptr(), _stream()),
+              "sempyr_l1_mean")
+        ctx.save_for_backward(a, b, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled() and g.requires_grad:
+            raise NotImplementedError("double backward through the L1 loss is not part of the hot path")
+        a, b, m = ctx.saved_tensors
+        g = _req(g, "grad")
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if ga is None and gb is None:
+            return None, None, None
+        check(L.sempyr_l1_mean_bwd(a.data_ptr(), b.data_ptr(), _p(m), g.data_ptr(), a.numel(), _p(ga), _p(gb), _stream()),
+              "sempyr_l1_mean_bwd")
+        return ga, gb, None
+
+
+def l1_mean(a, b, mask=None):
+    """nn.L1Loss()(a*mask, b*mask) in one pass (train_model.py:217-221) ; mask=None: nn.L1Loss()(a, b)
+    (train_model.py:109 ; train_feature_creation_gen.py:47,50)."""
+    return _L1Mean.apply(a, b, mask)
+
+
+class _GPLoss(Function):
+    """mean_b (||grad_b||_2 - 1)^2 (train_model.py:58-66)."""
+
+    @staticmethod
+    def forward(ctx, grad):
+        grad = _req(grad, "gradient")
+        rows = grad.shape[0]
+        n = grad.numel() // rows
+        norms = torch.empty(rows, dtype=torch.float32, device=grad.device)
+        gp = torch.empty((), dtype=torch.float32, device=grad.device)
+        check(L.sempyr_gp_fwd(grad.data_ptr(), rows, n, norms.data_ptr(), gp.data_ptr(), _stream()), "sempyr_gp_fwd")
+        ctx.save_for_backward(grad, norms)
+        return gp
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled() and g.requires_grad:
+            raise NotImplementedError("third-order derivatives are not part of the hot path")
+        grad, norms = ctx.saved_tensors
+        g = _req(g, "grad")
+        rows = grad.shape[0]
+        out = torch.empty_like(grad)
+        check(L.sempyr_gp_bwd(grad.data_ptr(), norms.data_ptr(), g.data_ptr(), rows, grad.numel() // rows, out.data_ptr(),
+                              _stream()), "sempyr_gp_bwd")
+        return out
+
+
+def gp_loss(grad):
+    """one_mean_gp(grad) (train_model.py:63-66)."""
+    return _GPLoss.apply(grad)
+
+
+def lerp_rows(real, fake, alpha):
+    """real + alpha*(fake-real) with one alpha per sample (sample_line, train_model.py:51-55); the result
+    is detached by its only caller (train_model.py:70)."""
+    real = _req(real.detach(), "real"); fake = _req(fake.detach(), "fake")
+    if real.shape != fake.shape:
+        raise _lib.SempyrError("lerp_rows: shape mismatch")
+    alpha = _req(alpha.reshape(-1), "alpha")
+    rows = real.shape[0]
+    if alpha.numel() != rows:
+        raise _lib.SempyrError("lerp_rows: one alpha per sample expected")
+    out = torch.empty_like(real)
+    check(L.sempyr_lerp_rows(real.data_ptr(), fake.data_ptr(), alpha.data_ptr(), out.data_ptr(), rows, real.numel() // rows,
+                             _stream()), "sempyr_lerp_rows")
+    return out

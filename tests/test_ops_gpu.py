@@ -1,0 +1,263 @@
+"""Operator-level parity: every C-ABI kernel family against a plain torch fp32 CPU reference of the same
+op (tolerances stated per test).  These call through libsempyr_hip.so via the autograd Functions."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from semantic_pyramid_for_image_generation_amd import ops
+    return ops
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# (B, Cin, H, W, Cout, k, stride, pad, ups, bias)
+CONV_CASES = [
+    (2, 3, 32, 32, 64, 3, 1, 1, 0, True),       # D stem (res)
+    (2, 3, 32, 32, 64, 4, 2, 1, 0, True),       # D stem (default)
+    (2, 64, 32, 32, 64, 4, 2, 1, 0, True),      # D block
+    (2, 128, 8, 8, 256, 4, 2, 1, 0, True),
+    (3, 512, 4, 4, 1, 4, 1, 0, 0, True),        # D last conv (M=1, split-K)
+    (2, 64, 16, 16, 64, 3, 1, 1, 1, False),     # G residual conv with fused upsample
+    (2, 64, 16, 16, 64, 1, 1, 0, 1, False),     # G skip 1x1 with fused upsample
+    (2, 128, 8, 8, 64, 3, 1, 1, 0, False),
+    (2, 64, 32, 32, 3, 3, 1, 1, 0, True),       # G last conv (M=3)
+    (2, 3, 64, 64, 64, 7, 2, 3, 0, False),      # ResNet stem
+    (2, 64, 16, 16, 128, 3, 2, 1, 0, False),    # ResNet stage entry
+    (2, 64, 16, 16, 128, 1, 2, 0, 0, False),    # ResNet shortcut
+    (1, 5, 9, 11, 7, 3, 1, 1, 0, True),         # ragged everything
+    (2, 96, 6, 6, 96, 3, 1, 1, 0, False),       # Mpad = 96 -> 32-wide tiles
+    (1, 512, 8, 8, 512, 3, 1, 1, 0, False),     # deep K, split-K path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, case):
+    ops = _ops()
+    B, Cin, H, W, Cout, k, s, p, ups, has_bias = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g) if has_bias else None
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    xin = F.interpolate(xr, scale_factor=2, mode='nearest') if ups else xr
+    yr = F.conv2d(xin, wr, br, s, p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if has_bias else None
+    y = ops.conv2d(xd, wd, bd, s, p, upsample=bool(ups))
+    assert y.shape == yr.shape
+    y.backward(gy.to(dev))
+    tol = 2e-5     # fp32 MFMA = k-ordered fmaf chains; differences are summation-order only
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+    if has_bias:
+        assert rel_err(bd.grad, br.grad) < tol
+
+
+CONVT_CASES = [
+    (2, 128, 1, 1, 512, 4, 1, 0, False),   # G conv_block1: 1x1 -> 4x4
+    (2, 64, 4, 4, 64, 4, 2, 1, False),     # G deconv 4x4 s2
+    (2, 64, 16, 16, 3, 4, 2, 1, True),     # G default last_conv (bias)
+    (1, 6, 5, 7, 10, 4, 2, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d_fwd_bwd(dev, case):
+    ops = _ops()
+    B, Cin, H, W, Cout, k, s, p, has_bias = case
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g) if has_bias else None
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    yr = F.conv_transpose2d(xr, wr, br, s, p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if has_bias else None
+    y = ops.conv_transpose2d(xd, wd, bd, s, p)
+    assert y.shape == yr.shape
+    y.backward(gy.to(dev))
+    tol = 2e-5
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+    if has_bias:
+        assert rel_err(bd.grad, br.grad) < tol
+
+
+def test_conv_double_backward(dev):
+    """d/d(w, x) of || d conv(x,w) / dx ||-style penalty: the conv part of the WGAN-GP double backward."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 12, 12, generator=g); w = torch.randn(16, 8, 4, 4, generator=g) * 0.2
+    b = torch.randn(16, generator=g)
+
+    def run(conv, x, w, b):
+        x = x.clone().requires_grad_(True); w = w.clone().requires_grad_(True); b = b.clone().requires_grad_(True)
+        y = conv(x, w, b)
+        pred = (y * y).sum() * 0.5
+        gx, = torch.autograd.grad(pred, x, create_graph=True)
+        pen = (gx * gx).sum()
+        pen.backward()
+        return gx, x.grad, w.grad
+    ref = run(lambda x, w, b: F.conv2d(x, w, b, 2, 1), x, w, b)
+    out = run(lambda x, w, b: ops.conv2d(x, w, b, 2, 1), x.to(dev), w.to(dev), b.to(dev))
+    for o, r in zip(out, ref):
+        assert rel_err(o, r) < 5e-5
+
+
+NORM_KINDS = ['batch', 'instance', 'layer']
+
+
+def _torch_norm(kind, x, gam, bet, eps=1e-5):
+    if kind == 'batch':
+        return F.batch_norm(x, None, None, gam, bet, True, 0.1, eps)
+    if kind == 'instance':
+        return F.instance_norm(x, None, None, gam, bet, True, 0.1, eps)
+    return F.group_norm(x, 1, gam, bet, eps)
+
+
+@pytest.mark.parametrize("kind", NORM_KINDS)
+@pytest.mark.parametrize("shape", [(3, 8, 4, 4), (2, 5, 7, 9), (2, 4, 64, 64)])
+@pytest.mark.parametrize("act", ['none', 'lrelu'])
+def test_norm_fwd_bwd_bwdbwd(dev, kind, shape, act):
+    ops = _ops()
+    KIND = {'batch': ops.NORM_BATCH, 'instance': ops.NORM_INSTANCE, 'layer': ops.NORM_LAYER}[kind]
+    ACT = ops.ACT_LRELU if act == 'lrelu' else ops.ACT_NONE
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.3
+    gam = torch.rand(shape[1], generator=g) + 0.5; bet = torch.randn(shape[1], generator=g) * 0.1
+    gy0 = torch.randn(shape, generator=g); u0 = torch.randn(shape, generator=g)
+
+    def run(fn, x, gam, bet, gy, u):
+        x = x.clone().requires_grad_(True); gam = gam.clone().requires_grad_(True); bet = bet.clone().requires_grad_(True)
+        gy = gy.clone().requires_grad_(True)
+        y = fn(x, gam, bet)
+        gx, ggam, gbet = torch.autograd.grad(y, [x, gam, bet], gy, create_graph=True)
+        L = (gx * u).sum()
+        r_gy, r_x, r_gam = torch.autograd.grad(L, [gy, x, gam])
+        return y, gx, ggam, gbet, r_gy, r_x, r_gam
+
+    def ref_fn(x, gam, bet):
+        y = _torch_norm(kind, x, gam, bet)
+        return F.leaky_relu(y, 0.2) if act == 'lrelu' else y
+    ref = run(ref_fn, x.double(), gam.double(), bet.double(), gy0.double(), u0.double())
+    out = run(lambda x, gam, bet: ops.norm_act(x, gam, bet, KIND, ACT, 0.2), x.to(dev), gam.to(dev), bet.to(dev),
+              gy0.to(dev), u0.to(dev))
+    names = ['y', 'gx', 'ggamma', 'gbeta', 'dd_gy', 'dd_x', 'dd_gamma']
+    for n, o, r in zip(names, out, ref):
+        assert rel_err(o, r) < 2e-4, n     # fp32 statistics vs an fp64 reference
+
+
+def test_batchnorm_running_stats(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 6, 5, 5, generator=g) * 2 + 1
+    bn = torch.nn.BatchNorm2d(6)
+    bn.train()
+    yr = bn(x)
+    rm = torch.zeros(6, device=dev); rv = torch.ones(6, device=dev); nbt = torch.zeros((), dtype=torch.long, device=dev)
+    y = ops.norm_act(x.to(dev), bn.weight.detach().to(dev), bn.bias.detach().to(dev), ops.NORM_BATCH, ops.ACT_NONE, 0.0,
+                     1e-5, (rm, rv, nbt, 0.1))
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(rm, bn.running_mean) < 1e-5 and rel_err(rv, bn.running_var) < 1e-5
+    assert int(nbt) == 1
+
+
+def test_bn_eval_act_residual(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 6, 8, 8, generator=g); res = torch.randn(2, 6, 8, 8, generator=g)
+    gam, bet = torch.rand(6, generator=g) + 0.5, torch.randn(6, generator=g)
+    rm, rv = torch.randn(6, generator=g), torch.rand(6, generator=g) + 0.5
+    xr = x.clone().requires_grad_(True); rr = res.clone().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, rm, rv, gam, bet, False, 0.1, 1e-5) + rr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True); rd = res.to(dev).requires_grad_(True)
+    y = ops.bn_eval_act(xd, gam.to(dev), bet.to(dev), rm.to(dev), rv.to(dev), 1e-5, res=rd, act_kind=ops.ACT_RELU)
+    y.backward(gy.to(dev))
+    assert rel_err(y, yr) < 1e-5 and rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(rd.grad, rr.grad) < 1e-5
+
+
+def test_elementwise_and_pools(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(2, 5, 6, 10, generator=g); b = torch.randn(2, 5, 6, 10, generator=g)
+    ad = a.to(dev); bd = b.to(dev)
+    assert torch.equal(ops.mul(ad, bd).cpu(), a * b)
+    assert rel_err(ops.add_act(ad, bd, ops.ACT_RELU), F.relu(a + b)) == 0
+    assert rel_err(ops.act(ad, ops.ACT_LRELU, 0.2), F.leaky_relu(a, 0.2)) < 1e-7
+    assert rel_err(ops.act(ad, ops.ACT_TANH), torch.tanh(a)) < 1e-6
+    assert rel_err(ops.avg_pool2(ad), F.avg_pool2d(a, 2)) < 1e-6
+    assert torch.equal(ops.upsample2(ad).cpu(), F.interpolate(a, scale_factor=2, mode='nearest'))
+    # backward of pools / act (incl. double backward of lrelu and avg-pool, both linear in the incoming grad)
+    ar = a.clone().requires_grad_(True); adr = a.to(dev).requires_grad_(True)
+    gy = torch.randn(2, 5, 3, 5, generator=g)
+    F.avg_pool2d(F.leaky_relu(ar, 0.2), 2).backward(gy)
+    ops.avg_pool2(ops.act(adr, ops.ACT_LRELU, 0.2)).backward(gy.to(dev))
+    assert rel_err(adr.grad, ar.grad) < 1e-6
+    # max pool 3/2/1 incl. odd sizes
+    for shape in [(2, 3, 8, 8), (1, 2, 7, 9)]:
+        x = torch.randn(shape, generator=g)
+        xr = x.clone().requires_grad_(True); xd = x.to(dev).requires_grad_(True)
+        yr = F.max_pool2d(xr, 3, 2, 1); y = ops.max_pool3s2(xd)
+        assert torch.equal(y.cpu(), yr)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy); y.backward(gy.to(dev))
+        assert rel_err(xd.grad, xr.grad) < 1e-6
+    # normalize (true division) + its backward
+    mean = torch.tensor([0.485, 0.456, 0.406]); std = torch.tensor([0.229, 0.224, 0.225])
+    x = torch.rand(2, 3, 6, 6, generator=g)
+    xr = x.clone().requires_grad_(True); xd = x.to(dev).requires_grad_(True)
+    yr = (xr - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    y = ops.normalize(xd, mean.to(dev), std.to(dev))
+    assert rel_err(y, yr) < 1e-7
+    gy = torch.randn(yr.shape, generator=g); yr.backward(gy); y.backward(gy.to(dev))
+    assert rel_err(xd.grad, xr.grad) < 1e-6
+    # lerp
+    al = torch.rand(2, 1, 1, 1, generator=g)
+    assert rel_err(ops.lerp_rows(ad, bd, al.to(dev)), a + al * (b - a)) < 1e-6
+    # global average pool
+    assert rel_err(ops.global_avg_pool(ad), F.adaptive_avg_pool2d(a, 1)) < 1e-6
+
+
+def test_reductions(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    for n in [(2, 1, 1, 1), (3, 7, 5, 5), (2, 64, 64, 64)]:
+        a = torch.randn(n, generator=g); b = torch.randn(n, generator=g); m = (torch.rand(n, generator=g) > 0.4).float()
+        ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+        adr = a.to(dev).requires_grad_(True); bdr = b.to(dev).requires_grad_(True)
+        lr = -ar.mean() * 1.0 + F.l1_loss(ar * m, br * m) * 3 + F.l1_loss(ar, br)
+        ld = ops.mean(adr, -1.0) + ops.l1_mean(adr, bdr, m.to(dev)) * 3 + ops.l1_mean(adr, bdr)
+        assert rel_err(ld, lr) < 1e-5
+        lr.backward(); ld.backward()
+        assert rel_err(adr.grad, ar.grad) < 1e-5 and rel_err(bdr.grad, br.grad) < 1e-5
+    # gradient-penalty reduction and its backward
+    x = torch.randn(3, 3, 16, 16, generator=g)
+    xr = x.clone().requires_grad_(True); xd = x.to(dev).requires_grad_(True)
+    gr = ((xr.view(3, -1).norm(p=2, dim=1) - 1) ** 2).mean(); gd = ops.gp_loss(xd)
+    assert rel_err(gd, gr) < 1e-5
+    (gr * 10).backward(); (gd * 10).backward()
+    assert rel_err(xd.grad, xr.grad) < 1e-5
+
+
+def test_no_cpu_fallback():
+    from semantic_pyramid_for_image_generation_amd import ops, _lib
+    with pytest.raises(_lib.SempyrError):
+        ops.conv2d(torch.randn(1, 3, 8, 8), torch.randn(4, 3, 3, 3), None, 1, 1)

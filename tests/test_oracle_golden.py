@@ -1,0 +1,179 @@
+"""The CPU oracle against fixtures produced by the reference's own code (oracle/gen_golden.py).
+This is what pins the oracle; the GPU tests then compare the HIP path with the oracle."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import check_summary, load_json, load_npz
+from oracle import masks as omasks
+from oracle import nets, recipes, steps
+from oracle.resnet18_cpu import ResNet18
+
+torch.set_num_threads(8)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_masks_bit_exact():
+    gold = load_json('masks.json')
+    shapes = recipes.tap_shapes(2)
+    for case in gold['cases']:
+        rng = random.Random(case['seed'])
+        is1, _ = None, None
+        tt = rng.choices([1, 2], [0.6, 0.4])
+        assert tt == case['train_type'] and (tt == 1) is case['train_type_eq_1'] is False      # quirk Q1
+        ms, _ = omasks.masks_part2(shapes, case['L'], rng)
+        assert rng.random() == case['next_random']                 # same number of RNG draws consumed
+        assert [sha(m) for m in ms] == case['sha256']
+        assert all(m.sum() == 0 for m in ms[case['L']:])           # quirk Q2: chosen layer is zeroed too
+    for c in gold['part1']:
+        assert [sha(m) for m in omasks.masks_part1(shapes, c['L'])] == c['sha256']
+    g = torch.Generator().manual_seed(gold['isolate']['seed'])
+    feats = [torch.rand(s, generator=g).numpy() for s in recipes.tap_shapes(1)]
+    assert [sha(m) for m in omasks.isolate_layer(feats, gold['isolate']['selected'])] == gold['isolate']['sha256']
+    c = gold['cropped']
+    m = np.ones(c['shape'], np.float32)
+    r0, r1, c0, c1 = omasks.crop_window(c['crop'], c['shape'][2], c['shape'][3], c['w1'], c['w2'])
+    m[:, :, r0:r1, c0:c1] = c['data']
+    assert sha(m) == c['sha256']
+
+
+def _ref_style_module(kind, *args):
+    """Build parameters with torch.nn containers in the reference's construction order.  Uses the
+    product package's container classes on CPU (construction needs no GPU) so the same seed reproduces
+    the reference's init (checked through the fixture's param_checksum)."""
+    from semantic_pyramid_for_image_generation_amd import discriminator, featuresCreatorGen, generator
+    cls = {'G': generator.Generator, 'D': discriminator.Discriminator, 'LU': featuresCreatorGen.LevelUpFeaturesGenerator,
+           'FD': featuresCreatorGen.FeaturesDiscriminator}[kind]
+    m = cls(*args)
+    m.init_weights()
+    return m
+
+
+def _sd(m):
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("gen_type", ['res', 'default'])
+@pytest.mark.parametrize("mode", ['train', 'eval'])
+def test_generator_oracle(gen_type, mode):
+    store, meta = load_npz('modules.npz'), load_json('modules.json')
+    name = f'G_{gen_type}_{mode}'
+    seed = meta[name]['seed']
+    torch.manual_seed(seed)
+    m = _ref_style_module('G', gen_type)
+    from golden_util import param_checksum
+    assert abs(param_checksum(m) - meta[name]['param_checksum']) < 1e-6 * meta[name]['param_checksum']
+    z, feats, masks = recipes.generator_inputs(seed, 2)
+    if mode == 'eval':
+        recipes.perturb_bn_buffers(m, seed)
+    sd = _sd(m)
+    with torch.no_grad():
+        y = nets.generator_forward(sd, gen_type, z, feats, masks, training=(mode == 'train'))
+    check_summary(store, name, y, 2e-5)
+    if mode == 'train':
+        assert np.allclose(sd['conv_block2.block.1.running_mean'].numpy(), store[name + '.rm'], atol=1e-6)
+        assert np.allclose(sd['conv_block2.block.1.running_var'].numpy(), store[name + '.rv'], atol=1e-6)
+        assert int(sd['conv_block2.block.1.num_batches_tracked']) == meta[name]['nbt']
+
+
+@pytest.mark.parametrize("norm", ['instance_norm', 'batch_norm', 'layer_norm'])
+@pytest.mark.parametrize("dis_type", ['res', 'default'])
+def test_discriminator_oracle(norm, dis_type):
+    store, meta = load_npz('modules.npz'), load_json('modules.json')
+    name = f'D_{norm}_{dis_type}'
+    seed = meta[name]['seed']
+    torch.manual_seed(seed)
+    m = _ref_style_module('D', norm, dis_type)
+    x = recipes.image_batch(seed, 2) * 2 - 1
+    with torch.no_grad():
+        y = nets.discriminator_forward(_sd(m), norm, dis_type, x, True)
+    assert np.allclose(y.numpy().reshape(-1), store[name], atol=2e-5)
+
+
+def test_feature_models_oracle():
+    store, meta = load_npz('modules.npz'), load_json('modules.json')
+    import os
+    from golden_util import GOLDEN
+    sd = torch.load(os.path.join(GOLDEN, 'features1_to_image.pt'), weights_only=True)
+    g = torch.Generator().manual_seed(meta['F1']['seed'])
+    x = torch.rand(2, 64, 64, 64, generator=g) * 2.0
+    with torch.no_grad():
+        y = nets.features1_to_image_forward(sd, x)
+    check_summary(store, 'F1', y, 2e-5)
+    shapes = recipes.tap_shapes(2)
+    for level in [2, 3, 4]:
+        seed = meta[f'LU{level}']['seed']
+        torch.manual_seed(seed)
+        lu = _ref_style_module('LU', level)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(shapes[level], generator=g)
+        with torch.no_grad():
+            y = nets.level_up_forward(_sd(lu), x, True)
+        check_summary(store, f'LU{level}', y, 2e-5)
+        for norm in ['instance_norm', 'batch_norm', 'layer_norm']:
+            for dis_type in (['res', 'default'] if norm == 'instance_norm' else ['res']):
+                torch.manual_seed(seed + 100)
+                fd = _ref_style_module('FD', norm, dis_type, level - 1)
+                xx = torch.rand(shapes[level - 1], generator=g)
+                with torch.no_grad():
+                    yy = nets.features_discriminator_forward(_sd(fd), norm, dis_type, level - 1, xx, True)
+                assert np.allclose(yy.numpy().reshape(-1), store[f'FD{level - 1}_{norm}_{dis_type}'], atol=2e-5)
+
+
+def test_classifier_restatement_matches_plain_torch_resnet():
+    """The ResNet-18 arithmetic is torchvision's (absent): pin the functional restatement against a plain
+    torch.nn implementation of the published architecture ("parity unpinned" by reference data)."""
+    model = recipes.make_resnet(5)
+    x = recipes.normalize_clf(recipes.image_batch(5, 1, size=64))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        logits, taps = nets.classifier_forward(sd, x)
+        ref = model(x)
+    assert torch.allclose(logits, ref, atol=1e-5)
+    assert [tuple(t.shape[1:]) for t in taps] == [(64, 32, 32), (64, 16, 16), (128, 8, 8), (256, 4, 4), (512, 2, 2), (512, 1, 1)]
+
+
+STEP_CASES = [('res', 'instance_norm', False), ('res', 'instance_norm', True), ('default', 'batch_norm', False),
+              ('default', 'layer_norm', False), ('res', 'batch_norm', False)]
+
+
+@pytest.mark.parametrize("case", STEP_CASES[:2] + STEP_CASES[3:4])
+def test_train_steps_oracle(case):
+    """D step, G step, D step at B=2 with the z / alpha draws the reference made."""
+    gen_type, norm, div = case
+    store, meta = load_npz('steps.npz'), load_json('steps.json')
+    name = f'steps_{gen_type}_{norm}_{"div" if div else "nodiv"}'
+    info = meta[name]
+    seed = info['seed']
+    torch.manual_seed(seed)
+    G = _ref_style_module('G', gen_type)
+    D = _ref_style_module('D', norm, gen_type)
+    clf_sd = {k: v.detach() for k, v in recipes.make_resnet(seed).state_dict().items()}
+    images = recipes.image_batch(seed, 2)
+    with torch.no_grad():
+        _, features = nets.classifier_forward(clf_sd, recipes.normalize_clf(images))
+    ms, _ = omasks.masks_part2([tuple(f.shape) for f in features], info['L'], random.Random(seed))
+    masks = [torch.from_numpy(m) for m in ms]
+    tr = steps.Trainer(_sd(G), _sd(D), clf_sd, gen_type, norm, use_diversity=div)
+    rn = [torch.from_numpy(store[f'{name}.randn{i}']) for i in range(info['n_randn'])]
+    ra = [torch.from_numpy(store[f'{name}.rand{i}']) for i in range(info['n_rand'])]
+    images_d = (images - 0.5) / 0.5
+    d1 = tr.d_step(images_d, features, masks, rn[0], ra[0])
+    g1 = tr.g_step(features, masks, info['L'], rn[1], rn[2] if div else None)
+    d2 = tr.d_step(images_d, features, masks, rn[-1], ra[1])
+    got = {}
+    for tag, dct in (('d1', d1), ('g1', g1), ('d2', d2)):
+        for k, v in dct.items():
+            got[f'{tag}.{k}'] = float(v)
+    for k, v in info['losses'].items():
+        assert abs(got[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, got[k], v)
+    for k, v in info['G_norms'].items():
+        assert abs(float(tr.g[k].detach().double().norm()) - v) <= 1e-4 * max(1.0, v), k
+    for k, v in info['D_norms'].items():
+        assert abs(float(tr.d[k].detach().double().norm()) - v) <= 1e-4 * max(1.0, v), k
