@@ -89,7 +89,7 @@ int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp
 
 /* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a
  * ConvTranspose2d whose forward this is). With ups=1 the result is the gradient in the upsampled
- * domain; reduce it with sempyr_sumpool2. */
+ * domain; reduce it with sempyr_pool2_down (scale 1). */
 int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, const float* wpacked_dgrad,
                         const int32_t* ktab_dgrad_dev, const float* bias, float* gx,
                         void* workspace, size_t workspace_bytes, void* stream);

@@ -573,17 +573,16 @@ extern "C" int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, c
 static int run_splitk_reduce(const float* slabs, float* out, const float* bias, int splits, long long numel,
                              int OHW, int OC, hipStream_t st)
 {
-    const int total4 = (int)(numel / 4);
-    if (total4 > 0) {
+    // float4 path only when every slab start (k * numel floats) stays 16-byte aligned
+    if (numel % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0) {
+        const int total4 = (int)(numel / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st,
                            slabs, out, bias, splits, numel, total4, OHW, OC);
-        SEMPYR_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(splitk_reduce_tail_kernel, dim3(ceil_div(numel, 256)), dim3(256), 0, st,
+                           slabs, out, bias, splits, numel, 0, (int)numel, OHW, OC);
     }
-    if (numel % 4) {
-        hipLaunchKernelGGL(splitk_reduce_tail_kernel, dim3(1), dim3(256), 0, st,
-                           slabs, out, bias, splits, numel, total4 * 4, (int)numel, OHW, OC);
-        SEMPYR_CHECK_LAUNCH();
-    }
+    SEMPYR_CHECK_LAUNCH();
     return 0;
 }
 
