@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — WGAN-GP training loop throughput (BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): reference train_model.py loop body, gen-type res, instance_norm critic,
+GP weight 10, batch 16 per GPU, synthetic 256x256 images resident in HBM, seeded random-init G/D/ResNet18
+(no trained weights ship).  One *step* = one cycle of the reference schedule = 5 loop iterations
+(classifier taps + masks + D step each; a G step in the first one) — train_model.py:300-349.
+`value` = loop iterations per second over all ranks (5 * K * N / seconds).
+
+Extra objects on the same JSON line: `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM
+convolution; per-launch HIP-event timing inside the timed region), `cpu_baseline` (the CPU oracle port timed on
+the host cores, rank 0 / N=1 only) and the eval images/sec of the eval_model.py loop.
+"""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+from argparse import Namespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+# SURVEY.md §8(d) algorithmic FLOPs (2 FLOP/MAC, reference's wasted work excluded), per sample:
+F_G, F_D, F_C = 19.053e9, 1.703e9, 4.738e9
+D_STEP_FLOPS = F_C + F_G + 12 * F_D            # 44.23 GFLOP / sample
+G_STEP_FLOPS = 3 * F_G + 2 * F_D + 2 * F_C     # 70.04 GFLOP / sample
+G_STEP_DIV_FLOPS = 6 * F_G + 2 * F_D + 2 * F_C
+EVAL_FLOPS_PER_IMAGE = F_G + F_C / 16
+
+
+def build_models(device, gen_type, norm, seed=0):
+    from semantic_pyramid_for_image_generation_amd.classifier import Classifier, resnet18
+    from semantic_pyramid_for_image_generation_amd.discriminator import Discriminator
+    from semantic_pyramid_for_image_generation_amd.generator import Generator
+    torch.manual_seed(seed)
+    G = Generator(gen_type); G.init_weights()
+    D = Discriminator(norm, gen_type); D.init_weights()
+    C = Classifier(resnet18(365))
+    G.to(device); D.to(device); C.to(device).eval()
+    for p in C.parameters():
+        p.requires_grad_(False)
+    return G, D, C
+
+
+def cpu_baseline(batch, diversity):
+    """The oracle (CPU restatement, kind 'port') on the host cores: 1 D step + 1 G step at the bench batch size,
+    combined with the reference schedule (5 D + 1 G per cycle)."""
+    from oracle import masks as omasks
+    from oracle import nets, recipes, steps
+    from semantic_pyramid_for_image_generation_amd.discriminator import Discriminator
+    from semantic_pyramid_for_image_generation_amd.generator import Generator
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    G = Generator('res'); G.init_weights()
+    D = Discriminator('instance_norm', 'res'); D.init_weights()
+    clf_sd = {k: v.detach() for k, v in recipes.make_resnet(0).state_dict().items()}
+    tr = steps.Trainer(G.state_dict(), D.state_dict(), clf_sd, 'res', 'instance_norm', use_diversity=diversity)
+    images = recipes.image_batch(0, batch)
+    t0 = time.time()
+    with torch.no_grad():
+        _, feats = nets.classifier_forward(clf_sd, recipes.normalize_clf(images))
+    t_clf = time.time() - t0
+    ms, _ = omasks.masks_part2([tuple(f.shape) for f in feats], 3, random.Random(0))
+    masks = [torch.from_numpy(m) for m in ms]
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(batch, 128, 1, 1, generator=g); z2 = torch.randn(batch, 128, 1, 1, generator=g)
+    alpha = torch.rand(batch, 1, 1, 1, generator=g)
+    images_d = (images - 0.5) / 0.5
+    t0 = time.time(); tr.d_step(images_d, feats, masks, z, alpha); t_d = time.time() - t0
+    t0 = time.time(); tr.g_step(feats, masks, 3, z, z2 if diversity else None); t_g = time.time() - t0
+    cycle = 5 * (t_clf + t_d) + t_g
+    return {"value": 5.0 / cycle, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU restatement) at batch {batch}: 1 classifier pass {t_clf:.2f}s + 1 D step {t_d:.2f}s "
+                      f"+ 1 G step {t_g:.2f}s, combined as 5*(clf+D)+G per cycle",
+            "torch": torch.__version__}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--gen-type', default='res', choices=['res', 'default'])
+    ap.add_argument('--discriminator-norm', default='instance_norm')
+    ap.add_argument('--use-diversity-loss', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-eval', action='store_true')
+    a = ap.parse_args()
+
+    from semantic_pyramid_for_image_generation_amd import _lib, eval_model, parallel
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    device = parallel.init_device()
+    rank, world = parallel.rank(), parallel.world_size()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+
+    G, D, C = build_models(device, a.gen_type, a.discriminator_norm)
+    parallel.broadcast_module(G); parallel.broadcast_module(D); parallel.broadcast_module(C)
+    tm.args = Namespace(use_diversity_loss=a.use_diversity_loss, gradient_penalty_weight=10.0)
+    d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
+    crit = tm.L1Loss()
+    g_opt = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    normalizer_clf = tm.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    normalizer_d = tm.Normalize([0.5, 0.5, 0.5], [0.5, 0.5, 0.5])
+
+    B = a.batch
+    gen = torch.Generator().manual_seed(1234 + rank)
+    pool = [torch.rand(B, 3, 256, 256, generator=gen).to(device) for _ in range(5)]    # resident in HBM
+    torch.manual_seed(100 + rank)          # rank-distinct z / alpha
+    random.seed(0)                         # identical layer / crop draws on every rank
+    it = [0]
+
+    def loop_iteration():
+        """body of train_model.py:300-349 without logging / checkpoint I/O"""
+        it[0] += 1
+        train_type = random.choices([1, 2], [0.6, 0.4])
+        images = pool[it[0] % len(pool)]
+        images_d = normalizer_d(images)
+        with torch.no_grad():
+            _, features = C(normalizer_clf(images))
+        L = random.randint(1, len(features) - 2)
+        masks = [f.clone() for f in features]
+        if train_type == 1:
+            tm.setMasksPart1(masks, device, L)
+        else:
+            tm.setMasksPart2(masks, device, L)
+        tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks)
+        if it[0] % 5 == 1:
+            tm.train_generator(G, D, g_loss_fn, g_opt, B, features, crit, L, C, normalizer_clf, crit, crit, masks, train_type)
+
+    def cycle():
+        for _ in range(5):
+            loop_iteration()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        cycle()
+    timing = not a.no_kernel_timing
+    barrier()
+    if timing:
+        _lib.check(_lib.lib.sempyr_profile_begin(4096 * max(a.steps, 1)), "sempyr_profile_begin")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cycle()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kms, kl, kf = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+    if timing:
+        _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # eval_model.py loop (BASELINE configs[0] shape: batch 8, 4 levels x 4 noises) — images/sec
+    eval_ips = None
+    if not a.no_eval:
+        G.eval()
+        src = pool[0][:8]
+        eval_model.synthesize_batch(G, C, src, normalizer_clf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            eval_model.synthesize_batch(G, C, src, normalizer_clf)
+        torch.cuda.synchronize()
+        eval_ips = reps * 128 / (time.perf_counter() - t1)
+        if world > 1:
+            t = torch.tensor([eval_ips], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t)
+            eval_ips = float(t.item())
+
+    if rank == 0:
+        iters = 5 * a.steps
+        cycle_flops = B * (5 * D_STEP_FLOPS + (G_STEP_DIV_FLOPS if a.use_diversity_loss else G_STEP_FLOPS))
+        out = {
+            "metric": "WGAN-GP train loop iterations/sec (train_model.py loop body; 1 D step per iteration, 1 G step every 5)",
+            "value": iters * world / elapsed, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train_model.py cycle = 5 loop iterations (5 D steps + 1 G step), gen-type {a.gen_type}, "
+                                   f"{a.discriminator_norm}, GP weight 10, batch {B}/GPU, 256x256"
+                                   + (", diversity loss" if a.use_diversity_loss else ""),
+                       "iters_per_step": 5, "batch_per_gpu": B, "parallelism": f"dp{world}",
+                       "weights": "seeded random init (trained blobs are not shipped)"},
+        }
+        if eval_ips is not None:
+            out["eval_images_per_sec"] = eval_ips
+            out["eval_config"] = "eval_model.py loop, gen-type res, batch 8, 4 levels x 4 noises, classifier pass included"
+        if timing and kl.value > 0:
+            achieved = cycle_flops * a.steps / (kms.value * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv fwd/dgrad/wgrad)",
+                               "launches": int(kl.value), "avg_launch_us": 1000.0 * kms.value / kl.value,
+                               "kernel_ms_total": kms.value, "kernel_time_share": kms.value * 1e-3 / elapsed,
+                               "flops_per_cycle_survey": cycle_flops, "flops_counted_2MNK": kf.value,
+                               "achieved_counted": kf.value / (kms.value * 1e-3) / 1e12}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, a.use_diversity_loss)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -104,7 +104,7 @@ int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, const float*
  * Normalisation: BatchNorm2d (train) / InstanceNorm2d(affine) / GroupNorm(1,C)
  * Tensors are seen as rows = N*C of len = H*W. `rowbuf` receives four per-row arrays
  * [mean_row | rstd_row | scale_row | shift_row] (each N*C floats); apply them with
- * sempyr_affine_act. Replaces nn.BatchNorm2d generator.py:28, and get_norm_layer
+ * sempyr_affine_act(x, mean_row, scale_row, shift_row, ...): y = (x - mean)*rstd*gamma + beta. Replaces nn.BatchNorm2d generator.py:28, and get_norm_layer
  * discriminator.py:16-26 (+ their autograd backward and double backward used by the gradient
  * penalty train_model.py:69-76).
  * ---------------------------------------------------------------------------------------- */
@@ -140,11 +140,11 @@ int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, const float* 
 /* ------------------------------------------------------------------------------------------
  * Elementwise (HBM-bound) kernels.
  * ---------------------------------------------------------------------------------------- */
-/* y = act(x*scale_row[r] + shift_row[r] + res); scale/shift (both or neither) and res optional.
+/* y = act((x - sub_row[r])*scale_row[r] + shift_row[r] + res); sub optional, scale/shift both or neither, res optional.
  * Replaces norm apply + nn.ReLU/LeakyReLU/Tanh (generator.py:29,48,57,120; discriminator.py:39,56,
  * 99,102) and the residual adds generator.py:56,87 ; discriminator.py:63. */
-int sempyr_affine_act(const float* x, const float* scale_row, const float* shift_row, const float* res,
-                      float* y, int rows, int len, int act, float slope, void* stream);
+int sempyr_affine_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
+                      const float* res, float* y, int rows, int len, int act, float slope, void* stream);
 /* g' = gy*act'(y); gx = g'*scale_row (NULL -> 1), gres = g' ; either output may be NULL. */
 int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_row, float* gx, float* gres,
                           int rows, int len, int act, float slope, void* stream);
@@ -185,6 +185,15 @@ int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp,
 int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int rows, int len, float* out, void* stream);
 /* out[c] = scale * sum_{n,hw} x[n][c][hw] : conv bias gradient ; scratch = N*C floats */
 int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, float* scratch, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (no counterpart in the reference; used by bench.py only).  Between begin and end
+ * every implicit-GEMM launch is bracketed by HIP events on its own stream; end synchronises and returns
+ * the summed kernel time, the launch count and the algorithmic FLOPs (2*M*N*K) of those launches.
+ * ---------------------------------------------------------------------------------------- */
+int sempyr_profile_begin(int max_launches);
+int sempyr_profile_end(double* kernel_ms, int64_t* launches, double* flops);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ SIGNATURES = {
     "sempyr_bn_eval_coeffs": [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P],
     "sempyr_norm_bwd": [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
     "sempyr_norm_bwd_bwd": [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
-    "sempyr_affine_act": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_affine_act": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
     "sempyr_affine_act_bwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
     "sempyr_mul": [_P, _P, _P, c_int64, _P],
     "sempyr_axpby": [_P, _P, c_float, c_float, _P, c_int64, _P],
@@ -69,6 +69,8 @@ SIGNATURES = {
     "sempyr_gp_fwd": [_P, c_int, c_int, _P, _P, _P],
     "sempyr_gp_bwd": [_P, _P, _P, c_int, c_int, _P, _P],
     "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, _P, _P],
+    "sempyr_profile_begin": [c_int],
+    "sempyr_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
 }
 
 

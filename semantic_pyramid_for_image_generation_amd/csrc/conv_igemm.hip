@@ -17,6 +17,9 @@
 // Split-K partial tiles go to caller-provided slabs and are summed in a fixed order
 // (deterministic: no float atomics anywhere).
 #include "common.h"
+#include <mutex>
+#include <stdlib.h>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -50,6 +53,7 @@ struct IgemmParams {
     int M, Mpad, N, K, Kpad;
     int XCHW;              // per-sample element stride of the gathered tensor
     int XW;                // physical row length of the gathered tensor
+    int XHW;               // physical plane size of the gathered tensor
     int GH, GW;            // logical gather-space extent (physical << ups)
     int ups;
     int SY, SX;            // gather coordinate = q*S + d
@@ -58,19 +62,22 @@ struct IgemmParams {
     int OCHW, OHW, OW;     // GATHER output tensor geometry
     int OSY, OSX, OPY, OPX;
     int ldc;               // WGRAD slab row length
-    int nchunks, chunks_per_split;
+    int nchunks, chunks_per_split, nsplits;
     long long slab_stride; // elements between split slabs
 };
 
-template <int BM, int BN, int WM, int WN, int MODE>
+// UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
+// indices of a GATHER chunk (resp. the consecutive columns a WGRAD thread owns) share one filter tap: the bounds test
+// and the spatial offset are computed once per chunk and every load is base + per-channel constant. Without it
+// (RGB stems, Cin = 3) each element is decoded separately.
+template <int BM, int BN, int WM, int WN, int MODE, bool UT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int PAD = (MODE == MODE_WGRAD) ? 2 : 0;
+    constexpr int PAD = (MODE == MODE_WGRAD) ? (UT ? 1 : 2) : 0;
     constexpr int LDA = BM + PAD, LDB = BN + PAD;
     constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;
-    constexpr int NTAB = (MODE == MODE_WGRAD) ? 2 * BN : 0;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS) + NTAB];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
     float* const As = smem;
     float* const Bs = smem + 2 * A_ELEMS;
 
@@ -79,16 +86,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so the
-    // m-tiles that re-read one activation tile are given ids 8 apart -> same L2.
+    // Workgroup -> (tile, split). Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an XCD/L2):
+    //  * no split-K: the m-tiles that re-read one activation tile get ids 8 apart -> same L2;
+    //  * split-K: the split index is the fastest-varying part of the id, so the splits of a tile (which share nothing)
+    //    spread over all XCDs.  (With few tiles and the split in blockIdx.y, whole XCDs would receive no work.)
     const int MT = (p.Mpad + BM - 1) / BM;
-    const int id = blockIdx.x;
-    const int m_tile = (id >> 3) % MT;
-    const int n_tile = ((id >> 3) / MT) * 8 + (id & 7);
+    int id = blockIdx.x, split = 0;
+    int m_tile, n_tile;
+    if (p.nsplits > 1) {
+        split = id % p.nsplits; id /= p.nsplits;
+        m_tile = id % MT; n_tile = id / MT;
+    } else {
+        m_tile = (id >> 3) % MT;
+        n_tile = ((id >> 3) / MT) * 8 + (id & 7);
+    }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     if (n0 >= p.N) return;                                   // uniform for the whole workgroup
 
-    const int split = blockIdx.y;
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(c_begin + p.chunks_per_split, p.nchunks);
 
@@ -101,44 +115,46 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---------------- per-thread load state ----------------
-    // GATHER mode: A tile = BK x BM floats of packed weights (float4 copies);
-    //              B tile: thread owns column n_local, rows krow0 + i*KSTEP.
+    // GATHER: A tile = BK x BM floats of packed weights (float4 copies); B tile: thread owns pixel column n_local,
+    //         reduction rows krow0 + i*KSTEP.
     constexpr int A_V4 = BK * BM / 4;
     constexpr int A_PER = (A_V4 + 255) / 256;
-    constexpr int KSTEP = (BN >= 256) ? 1 : 256 / BN;          // BN in {128, 256}
+    constexpr int KSTEP = (BN >= 256) ? 1 : 256 / BN;          // BN in {64, 128, 256}
     constexpr int B_PER = BK / KSTEP;
-    // WGRAD mode: thread owns reduction row k_local = tid % 16; columns (tid/16) + 16*i.
+    // WGRAD: thread owns pixel (reduction row) k_local = tid % 16 and WA_PER rows of gy / WB_PER columns of x.
     constexpr int WA_PER = BM / 16, WB_PER = BN / 16;
     constexpr int RA = (MODE == MODE_GATHER) ? A_PER * 4 : WA_PER;
     constexpr int RB = (MODE == MODE_GATHER) ? B_PER : WB_PER;
     float ra[RA], rb[RB];
+    unsigned ok_a = 0u, ok_b = 0u;     // validity bits of the staged elements; applied when they are written to LDS,
+                                       // so nothing consumes a load result before the MFMAs of the current chunk
 
     // GATHER-mode column decode (fixed for the whole K loop)
-    int g_ybase = 0, g_xbase = 0, g_off = 0;
-    bool g_valid = false;
-    int g_krow0 = 0;
+    int g_ybase = 0, g_xbase = 0, g_off = 0, g_krow0 = 0;
     if constexpr (MODE == MODE_GATHER) {
         const int n_local = tid % BN;
         g_krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
         const int n = n0 + n_local;
-        g_valid = n < p.N;
-        const int nn = g_valid ? n : 0;
+        const bool valid = n < p.N;
+        const int nn = valid ? n : 0;
         const int b = nn / p.QHW;
         const int r = nn - b * p.QHW;
         const int qy = r / p.QW;
         const int qx = r - qy * p.QW;
-        g_ybase = g_valid ? qy * p.SY : -(1 << 20);             // invalid column never passes the bound test
+        g_ybase = valid ? qy * p.SY : -(1 << 20);               // invalid column never passes the bound test
         g_xbase = qx * p.SX;
         g_off = b * p.XCHW;
     }
+    // WGRAD-mode column decode: the gather-table entries of this thread's columns are loop-invariant -> registers
+    constexpr int NTAB = (MODE == MODE_WGRAD) ? (UT ? 1 : WB_PER) : 1;
+    int2 w_tab[NTAB];
+    const int w_c0 = tid >> 4;
     if constexpr (MODE == MODE_WGRAD) {
-        // stage this tile's n-table (fixed per workgroup) in LDS
-        int2* ntab = reinterpret_cast<int2*>(smem + 2 * (A_ELEMS + B_ELEMS));
-        for (int i = tid; i < BN; i += 256) {
-            const int n = n0 + i;
-            ntab[i] = (n < p.N) ? p.ktab[n] : make_int2(0, (int)0x80008000);   // dy=dx=-32768: always out of range
+#pragma unroll
+        for (int i = 0; i < NTAB; ++i) {
+            const int n = UT ? (n0 + w_c0 * WB_PER) : (n0 + w_c0 + 16 * i);
+            w_tab[i] = (n < p.N) ? p.ktab[n] : make_int2(0, (int)0x80008000);  // dy=dx=-32768: always out of range
         }
-        __syncthreads();
     }
 
     auto load_tiles = [&](int chunk) {
@@ -156,19 +172,35 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 }
                 ra[i * 4 + 0] = v.x; ra[i * 4 + 1] = v.y; ra[i * 4 + 2] = v.z; ra[i * 4 + 3] = v.w;
             }
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int k = k0 + g_krow0 + i * KSTEP;            // wave-uniform -> scalar table load
-                const int2 e = p.ktab[k];
-                const int iy = g_ybase + (e.y >> 16);
-                const int ix = g_xbase + (int)(short)(e.y & 0xffff);
+            if constexpr (UT) {
+                const int2 e0 = p.ktab[k0];                        // uniform: the whole chunk is one tap
+                const int iy = g_ybase + (e0.y >> 16);
+                const int ix = g_xbase + (int)(short)(e0.y & 0xffff);
                 const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
-                const int off = g_off + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
-                rb[i] = ok ? p.X[off] : 0.f;
+                // out-of-range pixels read offset 0 of the channel plane (always mapped) and are zeroed when staged
+                const int sp = ok ? g_off + (iy >> p.ups) * p.XW + (ix >> p.ups) : 0;
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const int ch = p.ktab[k0 + g_krow0 + i * KSTEP].x;   // wave-uniform -> scalar load, scalar base
+                    rb[i] = (p.X + ch)[sp];
+                }
+                ok_b = ok ? 0xffffffffu : 0u;
+            } else {
+                unsigned okb = 0u;
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const int2 e = p.ktab[k0 + g_krow0 + i * KSTEP];
+                    const int iy = g_ybase + (e.y >> 16);
+                    const int ix = g_xbase + (int)(short)(e.y & 0xffff);
+                    const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+                    const int off = g_off + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
+                    rb[i] = p.X[ok ? off : 0];                     // branch-free: element 0 is always mapped
+                    okb |= (ok ? 1u : 0u) << i;
+                }
+                ok_b = okb;
             }
         } else {
             const int k_local = tid & 15;
-            const int c0 = tid >> 4;
             const int k = k0 + k_local;
             const bool kv = k < p.K;
             const uint32_t kk = kv ? (uint32_t)k : 0u;
@@ -176,26 +208,52 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             const uint32_t r = kk - b * (uint32_t)p.QHW;
             const uint32_t qy = p.dQW.div(r);
             const uint32_t qx = r - qy * (uint32_t)p.QW;
-            // A: gy[b][m][r]
-            const float* ap = p.A + (size_t)b * p.M * p.QHW + r;
-#pragma unroll
-            for (int i = 0; i < WA_PER; ++i) {
-                const int m = m0 + c0 + 16 * i;
-                ra[i] = (kv && m < p.M) ? ap[(size_t)m * p.QHW] : 0.f;
-            }
             const int ybase = kv ? (int)qy * p.SY : -(1 << 20);
             const int xbase = (int)qx * p.SX;
             const int xoff = (int)b * p.XCHW;
-            const int2* ntab = reinterpret_cast<const int2*>(smem + 2 * (A_ELEMS + B_ELEMS));
+            unsigned oka = 0u;
+            if constexpr (UT) {
+                // A: gy[b][m][r], rows m = mrow0 + i
+                const int mrow0 = m0 + w_c0 * WA_PER;
+                const int a_off = ((int)b * p.M + mrow0) * p.QHW + (int)r;
 #pragma unroll
-            for (int i = 0; i < WB_PER; ++i) {
-                const int2 e = ntab[c0 + 16 * i];
+                for (int i = 0; i < WA_PER; ++i) {
+                    const bool ok = kv && (mrow0 + i) < p.M;
+                    ra[i] = p.A[ok ? a_off + i * p.QHW : 0];
+                    oka |= (ok ? 1u : 0u) << i;
+                }
+                // B: x[b][ci0 + i][pixel shifted by this thread's tap]
+                const int2 e = w_tab[0];
                 const int iy = ybase + (e.y >> 16);
                 const int ix = xbase + (int)(short)(e.y & 0xffff);
                 const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
-                const int off = xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
-                rb[i] = ok ? p.X[off] : 0.f;
+                const int sp = ok ? xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups) : 0;
+#pragma unroll
+                for (int i = 0; i < WB_PER; ++i) rb[i] = (p.X + i * p.XHW)[sp];   // uniform base + one vgpr offset
+                ok_b = ok ? 0xffffffffu : 0u;
+            } else {
+                const float* ap = p.A + (size_t)b * p.M * p.QHW + r;
+#pragma unroll
+                for (int i = 0; i < WA_PER; ++i) {
+                    const int m = m0 + w_c0 + 16 * i;
+                    const bool ok = kv && m < p.M;
+                    ra[i] = ap[ok ? (size_t)m * p.QHW : 0];
+                    oka |= (ok ? 1u : 0u) << i;
+                }
+                unsigned okb = 0u;
+#pragma unroll
+                for (int i = 0; i < WB_PER; ++i) {
+                    const int2 e = w_tab[i];
+                    const int iy = ybase + (e.y >> 16);
+                    const int ix = xbase + (int)(short)(e.y & 0xffff);
+                    const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+                    const int off = xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
+                    rb[i] = p.X[ok ? off : 0];
+                    okb |= (ok ? 1u : 0u) << i;
+                }
+                ok_b = okb;
             }
+            ok_a = oka;
         }
     };
 
@@ -215,14 +273,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             }
             const int n_local = tid % BN;
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) bs[(g_krow0 + i * KSTEP) * LDB + n_local] = rb[i];
+            for (int i = 0; i < B_PER; ++i)
+                bs[(g_krow0 + i * KSTEP) * LDB + n_local] = ((ok_b >> i) & 1u) ? rb[i] : 0.f;
         } else {
             const int k_local = tid & 15;
-            const int c0 = tid >> 4;
 #pragma unroll
-            for (int i = 0; i < WA_PER; ++i) as[k_local * LDA + c0 + 16 * i] = ra[i];
+            for (int i = 0; i < WA_PER; ++i)
+                as[k_local * LDA + (UT ? w_c0 * WA_PER + i : w_c0 + 16 * i)] = ((ok_a >> i) & 1u) ? ra[i] : 0.f;
 #pragma unroll
-            for (int i = 0; i < WB_PER; ++i) bs[k_local * LDB + c0 + 16 * i] = rb[i];
+            for (int i = 0; i < WB_PER; ++i)
+                bs[k_local * LDB + (UT ? w_c0 * WB_PER + i : w_c0 + 16 * i)] = ((ok_b >> i) & 1u) ? rb[i] : 0.f;
         }
     };
 
@@ -236,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             const int buf = (c - c_begin) & 1;
             const bool more = (c + 1) < c_end;
             if (more) load_tiles(c + 1);                       // global loads in flight under the MFMAs
+            __builtin_amdgcn_sched_barrier(0);
             const float* as = As + buf * A_ELEMS + kh * LDA + wm * (TM * 32) + l31;
             const float* bs = Bs + buf * B_ELEMS + kh * LDB + wn * (TN * 32) + l31;
 #pragma unroll
@@ -251,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (more) store_tiles(buf ^ 1);
             __syncthreads();
         }
@@ -260,7 +322,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     // accumulator register r of lane l: column n = l%32, row m = (r&3) + 8*(r>>2) + 4*(l/32)
     float* out = p.Out + (size_t)split * p.slab_stride;
     const int l31 = lane & 31, kh = lane >> 5;
+    const bool full_m = (m0 + BM) <= p.M;                        // workgroup-uniform: no per-row guard needed
     if constexpr (MODE == MODE_GATHER) {
+        if (p.bias) {                                            // uniform; all bias loads issued before any use
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float bv[16];
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                    bv[r16] = p.bias[m < p.M ? m : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] += bv[r16];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (TN * 32) + j * 32 + l31;
@@ -272,13 +350,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             float* op = out + (size_t)b * p.OCHW + (qy * p.OSY + p.OPY) * p.OW + qx * p.OSX + p.OPX;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+                if (full_m) {
 #pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) {
-                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
-                    if (m < p.M) {
-                        float v = acc[i][j][r16];
-                        if (p.bias) v += p.bias[m];
-                        op[(size_t)m * p.OHW] = v;
+                    for (int r16 = 0; r16 < 16; ++r16)
+                        op[(size_t)(mb + (r16 & 3) + 8 * (r16 >> 2)) * p.OHW] = acc[i][j][r16];
+                } else {
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) {
+                        const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                        if (m < p.M) op[(size_t)m * p.OHW] = acc[i][j][r16];
                     }
                 }
             }
@@ -290,10 +371,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             if (n >= p.N) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+                if (full_m) {
 #pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) {
-                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
-                    if (m < p.M) out[(size_t)m * p.ldc + n] = acc[i][j][r16];
+                    for (int r16 = 0; r16 < 16; ++r16)
+                        out[(size_t)(mb + (r16 & 3) + 8 * (r16 >> 2)) * p.ldc + n] = acc[i][j][r16];
+                } else {
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) {
+                        const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                        if (m < p.M) out[(size_t)m * p.ldc + n] = acc[i][j][r16];
+                    }
                 }
             }
         }
@@ -365,7 +453,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2 };
+enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3 };
 
 inline int pick_cfg(int Mpad) {
     if (Mpad % 128 == 0) return CFG_128x128;
@@ -375,7 +463,13 @@ inline int pick_cfg(int Mpad) {
 inline void cfg_dims(int cfg, int& bm, int& bn) {
     if (cfg == CFG_128x128) { bm = 128; bn = 128; }
     else if (cfg == CFG_64x256) { bm = 64; bn = 256; }
+    else if (cfg == CFG_64x64) { bm = 64; bn = 64; }
     else { bm = 32; bn = 256; }
+}
+// WGRAD: the N dimension (Cin*taps) can be tiny (27 for an RGB stem, 64 for a 1x1 skip): use a narrow tile there
+inline int pick_cfg_wgrad(int Mpad, int Nn) {
+    if (Nn <= 64 && Mpad % 64 == 0) return CFG_64x64;
+    return pick_cfg(Mpad);
 }
 
 constexpr int TARGET_BLOCKS = 512;     // 2 workgroups per CU
@@ -387,7 +481,7 @@ inline void pick_splits(int tiles, int nchunks, int& splits, int& cps) {
         splits = (TARGET_BLOCKS + tiles - 1) / tiles;
         const int maxs = nchunks / MIN_CHUNKS_PER_SPLIT > 0 ? nchunks / MIN_CHUNKS_PER_SPLIT : 1;
         if (splits > maxs) splits = maxs;
-        if (splits > 256) splits = 256;
+        if (splits > 512) splits = 512;
     }
     cps = (nchunks + splits - 1) / splits;
     splits = (nchunks + cps - 1) / cps;                   // no empty splits
@@ -422,24 +516,56 @@ inline int phase_taps(int kdim, int s, int p, int ph, int& r, int& c) {
     return r < kdim ? (kdim - r + s - 1) / s : 0;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+// Opt-in kernel timing (bench.py's roofline leg): HIP events recorded on the launch stream around every
+// implicit-GEMM launch, plus the launch's algorithmic FLOPs (2*M*N*K on the unpadded dims).
+struct Profiler {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> events;     // pairs (start, stop)
+    struct Rec { int mode, bm, bn, M, N, K, splits; };
+    std::vector<Rec> recs;
+    size_t used = 0;
+    double flops = 0.0;
+};
+Profiler g_prof;
+
+template <int BM, int BN, int WM, int WN, int MODE, bool UT>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
     const int MT = (p.Mpad + BM - 1) / BM;
     const int NT = (p.N + BN - 1) / BN;
     const int NT8 = (NT + 7) / 8 * 8;
-    dim3 grid(MT * NT8, splits, 1);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(256), 0, st, p);
+    dim3 grid(splits > 1 ? MT * NT * splits : MT * NT8, 1, 1);
+    IgemmParams pp = p; pp.nsplits = splits;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_prof.on) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.used + 2 <= g_prof.events.size()) {
+            e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
+            g_prof.used += 2;
+            g_prof.flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+            g_prof.recs.push_back({MODE + (UT ? 0 : 2), BM, BN, p.M, p.N, p.K, splits});
+        }
+    }
+    if (e0) (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT>), grid, dim3(256), 0, st, pp);
+    if (e1) (void)hipEventRecord(e1, st);
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }
 
-template <int MODE>
-int launch_cfg(int cfg, const IgemmParams& p, int splits, hipStream_t st) {
+template <int MODE, bool UT>
+int launch_cfg_ut(int cfg, const IgemmParams& p, int splits, hipStream_t st) {
     switch (cfg) {
-        case CFG_128x128: return launch_igemm<128, 128, 2, 2, MODE>(p, splits, st);
-        case CFG_64x256:  return launch_igemm<64, 256, 1, 4, MODE>(p, splits, st);
-        default:          return launch_igemm<32, 256, 1, 4, MODE>(p, splits, st);
+        case CFG_128x128: return launch_igemm<128, 128, 2, 2, MODE, UT>(p, splits, st);
+        case CFG_64x256:  return launch_igemm<64, 256, 1, 4, MODE, UT>(p, splits, st);
+        case CFG_64x64:   return launch_igemm<64, 64, 2, 2, MODE, UT>(p, splits, st);
+        default:          return launch_igemm<32, 256, 1, 4, MODE, UT>(p, splits, st);
     }
+}
+// `uniform_tap`: the gathered tensor's channel count is a multiple of BK and K needs no padding (see the kernel)
+template <int MODE>
+int launch_cfg(int cfg, const IgemmParams& p, int splits, bool uniform_tap, hipStream_t st) {
+    return uniform_tap ? launch_cfg_ut<MODE, true>(cfg, p, splits, st) : launch_cfg_ut<MODE, false>(cfg, p, splits, st);
 }
 
 } // namespace
@@ -497,7 +623,7 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         const int Nn = (d->Cin * g.T + BK - 1) / BK * BK;       // = FWD Kpad: columns incl. padding
         plan->tab_off[0] = 0; plan->tab_entries = Nn;
         plan->Mpad = (d->Cout + 31) / 32 * 32;
-        plan->cfg = pick_cfg(plan->Mpad); cfg_dims(plan->cfg, bm, bn);
+        plan->cfg = pick_cfg_wgrad(plan->Mpad, Nn); cfg_dims(plan->cfg, bm, bn);
         plan->wpack_floats = 0;
         int cps;
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(Nn, bn), plan->Kpad[0] / BK, plan->splits[0], cps);
@@ -600,7 +726,7 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     IgemmParams p{};
     p.A = wp; p.X = x; p.ktab = reinterpret_cast<const int2*>(ktab);
     p.M = d->Cout; p.Mpad = pl.Mpad; p.N = d->B * pl.Ho * pl.Wo; p.K = pl.K[0]; p.Kpad = pl.Kpad[0];
-    p.XCHW = d->Cin * d->Hin * d->Win; p.XW = d->Win;
+    p.XCHW = d->Cin * d->Hin * d->Win; p.XW = d->Win; p.XHW = d->Hin * d->Win;
     p.GH = d->Hin << d->ups; p.GW = d->Win << d->ups; p.ups = d->ups;
     p.SY = p.SX = d->stride;
     p.QH = pl.Ho; p.QW = pl.Wo; p.QHW = pl.Ho * pl.Wo; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
@@ -611,7 +737,7 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     p.chunks_per_split = ceil_div(p.nchunks, splits);
     if (splits == 1) { p.Out = y; p.bias = bias; p.slab_stride = 0; }
     else { p.Out = (float*)ws; p.bias = nullptr; p.slab_stride = out_numel; }
-    if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, st)) return rc;
+    if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
     if (splits > 1) return run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, st);
     return 0;
 }
@@ -648,7 +774,7 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
         p.A = wp + (size_t)pl.tab_off[ph] * pl.Mpad;
         p.X = gy; p.ktab = reinterpret_cast<const int2*>(ktab) + pl.tab_off[ph];
         p.M = d->Cin; p.Mpad = pl.Mpad; p.N = d->B * QH * QW; p.K = pl.K[ph]; p.Kpad = pl.Kpad[ph];
-        p.XCHW = d->Cout * pl.Ho * pl.Wo; p.XW = pl.Wo; p.GH = pl.Ho; p.GW = pl.Wo; p.ups = 0;
+        p.XCHW = d->Cout * pl.Ho * pl.Wo; p.XW = pl.Wo; p.XHW = pl.Ho * pl.Wo; p.GH = pl.Ho; p.GW = pl.Wo; p.ups = 0;
         p.SY = p.SX = 1;
         p.QH = QH; p.QW = QW; p.QHW = QH * QW; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
         p.OCHW = d->Cin * GH * GW; p.OHW = GH * GW; p.OW = GW;
@@ -659,7 +785,7 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
         p.chunks_per_split = ceil_div(p.nchunks, ph_splits);
         ph_splits = splits;                                         // surplus splits write zeros
         p.Out = target; p.bias = splits == 1 ? bias : nullptr; p.slab_stride = splits > 1 ? in_numel : 0;
-        if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, ph_splits, st)) return rc;
+        if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, ph_splits, d->Cout % BK == 0, st)) return rc;
     }
     if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, st);
     return 0;
@@ -680,7 +806,7 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     IgemmParams p{};
     p.A = gy; p.X = x; p.ktab = reinterpret_cast<const int2*>(ktab);
     p.M = d->Cout; p.Mpad = pl.Mpad; p.N = Nn; p.K = pl.K[0]; p.Kpad = pl.Kpad[0];
-    p.XCHW = d->Cin * d->Hin * d->Win; p.XW = d->Win;
+    p.XCHW = d->Cin * d->Hin * d->Win; p.XW = d->Win; p.XHW = d->Hin * d->Win;
     p.GH = d->Hin << d->ups; p.GW = d->Win << d->ups; p.ups = d->ups;
     p.SY = p.SX = d->stride;
     p.QH = pl.Ho; p.QW = pl.Wo; p.QHW = pl.Ho * pl.Wo; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
@@ -689,10 +815,54 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     const int splits = pl.splits[0];
     p.chunks_per_split = ceil_div(p.nchunks, splits);
     p.Out = (float*)ws; p.slab_stride = (long long)d->Cout * Nn;
-    if (int rc = launch_cfg<MODE_WGRAD>(pl.cfg, p, splits, st)) return rc;
+    if (int rc = launch_cfg<MODE_WGRAD>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
     const int total = d->Cout * d->Cin * T;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st,
                        (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn);
     SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel-timing hooks (measurement only; never enabled by the product path)
+// ------------------------------------------------------------------------------------------
+extern "C" int sempyr_profile_begin(int max_launches)
+{
+    if (max_launches < 1) SEMPYR_FAIL("profile_begin: max_launches must be positive");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    while (g_prof.events.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) { sempyr_set_error("profile_begin: hipEventCreate: %s", hipGetErrorString(rc)); return (int)rc; }
+        g_prof.events.push_back(e);
+    }
+    g_prof.used = 0; g_prof.flops = 0.0; g_prof.recs.clear(); g_prof.on = true;
+    return 0;
+}
+
+extern "C" int sempyr_profile_end(double* kernel_ms, int64_t* launches, double* flops)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = false;
+    double ms = 0.0;
+    const char* dump = getenv("SEMPYR_PROFILE_DUMP");      // optional per-launch CSV (tuning aid)
+    FILE* df = dump ? fopen(dump, "w") : nullptr;
+    if (df) fprintf(df, "mode,bm,bn,M,N,K,splits,ms\n");
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        hipError_t rc = hipEventSynchronize(g_prof.events[i + 1]);
+        if (rc != hipSuccess) { sempyr_set_error("profile_end: hipEventSynchronize: %s", hipGetErrorString(rc)); return (int)rc; }
+        float t = 0.f;
+        rc = hipEventElapsedTime(&t, g_prof.events[i], g_prof.events[i + 1]);
+        if (rc != hipSuccess) { sempyr_set_error("profile_end: hipEventElapsedTime: %s", hipGetErrorString(rc)); return (int)rc; }
+        ms += t;
+        if (df && i / 2 < g_prof.recs.size()) {
+            const Profiler::Rec& r = g_prof.recs[i / 2];
+            fprintf(df, "%d,%d,%d,%d,%d,%d,%d,%.5f\n", r.mode, r.bm, r.bn, r.M, r.N, r.K, r.splits, t);
+        }
+    }
+    if (df) fclose(df);
+    if (kernel_ms) *kernel_ms = ms;
+    if (launches) *launches = (int64_t)(g_prof.used / 2);
+    if (flops) *flops = g_prof.flops;
     return 0;
 }

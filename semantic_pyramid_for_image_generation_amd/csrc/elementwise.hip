@@ -27,8 +27,9 @@ __device__ __forceinline__ float act_deriv_y(float y, int act, float slope) {
     }
 }
 
-// y = act(x * scale[row] + shift[row] + res)
-__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+// y = act((x - sub[row]) * scale[row] + shift[row] + res)      (sub optional)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sub,
+                                                         const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const float* __restrict__ res,
                                                          float* __restrict__ y, long long total, int len, int vec,
                                                          int act, float slope)
@@ -36,10 +37,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (vec) {
         if (i * 4 >= total) return;
-        float sc = 1.f, sh = 0.f;
-        if (scale) { const int row = (int)((i * 4) / len); sc = scale[row]; sh = shift[row]; }
+        float sc = 1.f, sh = 0.f, mu = 0.f;
+        if (scale) { const int row = (int)((i * 4) / len); sc = scale[row]; sh = shift[row]; if (sub) mu = sub[row]; }
         float4 v = reinterpret_cast<const float4*>(x)[i];
-        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+        v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh; v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
         if (res) { const float4 r = reinterpret_cast<const float4*>(res)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
         v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
         v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     } else {
         if (i >= total) return;
         float v = x[i];
-        if (scale) { const int row = (int)(i / len); v = v * scale[row] + shift[row]; }
+        if (scale) { const int row = (int)(i / len); v = (v - (sub ? sub[row] : 0.f)) * scale[row] + shift[row]; }
         if (res) v += res[i];
         y[i] = act_apply(v, act, slope);
     }
@@ -243,16 +244,17 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __rest
     hipLaunchKernelGGL(kernel, dim3(ceil_div((nthreads), 256)), dim3(256), 0, (st), __VA_ARGS__); \
     SEMPYR_CHECK_LAUNCH(); } while (0)
 
-extern "C" int sempyr_affine_act(const float* x, const float* scale_row, const float* shift_row, const float* res,
-                                 float* y, int rows, int len, int act, float slope, void* stream)
+extern "C" int sempyr_affine_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
+                                 const float* res, float* y, int rows, int len, int act, float slope, void* stream)
 {
     if (!x || !y) SEMPYR_FAIL("affine_act: null pointer");
     if ((scale_row == nullptr) != (shift_row == nullptr)) SEMPYR_FAIL("affine_act: scale and shift must both be given");
+    if (sub_row && !scale_row) SEMPYR_FAIL("affine_act: sub_row needs scale/shift");
     if (rows < 1 || len < 1) SEMPYR_FAIL("affine_act: bad dims");
     if (act < 0 || act > 3) SEMPYR_FAIL("affine_act: bad activation %d", act);
     const long long total = (long long)rows * len;
     const int vec = (len % 4 == 0) && aligned16(x) && aligned16(y) && (!res || aligned16(res));
-    LAUNCH_1D(affine_act_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, scale_row, shift_row, res, y, total, len, vec, act, slope);
+    LAUNCH_1D(affine_act_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, sub_row, scale_row, shift_row, res, y, total, len, vec, act, slope);
     return 0;
 }
 

@@ -114,7 +114,7 @@ __global__ void norm_finalize_kernel(int kind, const float* __restrict__ row_mea
         const int c = row % C;
         const float sc = rstd * gamma[c];
         mean_row[row] = mean; rstd_row[row] = rstd;
-        scale_row[row] = sc; shift_row[row] = beta[c] - mean * sc;
+        scale_row[row] = sc; shift_row[row] = beta[c];     // y = (x - mean_row) * scale_row + shift_row
     }
     if (kind == SEMPYR_NORM_BATCH && running_mean) {
         const float unbiased = m > 1.f ? m2 / (m - 1.f) : var;
@@ -200,10 +200,10 @@ __global__ void norm_bwd_finalize_kernel(int kind, const float* __restrict__ s1,
         const float abar = SA / m, s = SB / m;
         for (int i = 0; i < count; ++i) {
             const int row = start + i * stride;
-            const float r = rstd_row[row], mean = mean_row[row];
+            const float r = rstd_row[row];
             cA[row] = r * gamma[row % C];
             cB[row] = -r * r * s;
-            cC[row] = -r * abar + r * r * s * mean;
+            cC[row] = -r * abar;                       // gx = cA*gy' + cB*(x - mean) + cC
         }
     } else if (idx < ng + C) {
         const int c = idx - ng;
@@ -214,9 +214,9 @@ __global__ void norm_bwd_finalize_kernel(int kind, const float* __restrict__ s1,
     }
 }
 
-// gx = cA[row] * gy * act'(y) + cB[row] * x + cC[row]
+// gx = cA[row] * gy * act'(y) + cB[row] * (x - mean[row]) + cC[row]   (centred form: no cancellation against the mean)
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ x, const float* __restrict__ mean_row,
                                                              const float* __restrict__ cA, const float* __restrict__ cB,
                                                              const float* __restrict__ cC,
                                                              long long total, int len, int vec, int act, float slope,
@@ -226,9 +226,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     if (vec) {
         if (i * 4 >= total) return;
         const int row = (int)((i * 4) / len);
-        const float a = cA[row], b = cB[row], c = cC[row];
+        const float a = cA[row], b = cB[row], c = cC[row], mu = mean_row[row];
         float4 g = reinterpret_cast<const float4*>(gy)[i];
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 xv = reinterpret_cast<const float4*>(x)[i];
+        xv.x -= mu; xv.y -= mu; xv.z -= mu; xv.w -= mu;
         if (act != SEMPYR_ACT_NONE) {
             const float4 yv = reinterpret_cast<const float4*>(y)[i];
             g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
         const int row = (int)(i / len);
         float g = gy[i];
         if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[i], act, slope);
-        gx[i] = cA[row] * g + cB[row] * x[i] + cC[row];
+        gx[i] = cA[row] * g + cB[row] * (x[i] - mean_row[row]) + cC[row];
     }
 }
 
@@ -322,15 +323,15 @@ __global__ void norm_bwdbwd_finalize_kernel(int kind, const float* __restrict__ 
     for (int i = 0; i < count; ++i) {
         const int row = start + i * stride;
         const float gm = gamma[row % C];
-        const float r = rstd_row[row], mean = mean_row[row];
+        const float r = rstd_row[row];
         const float r2 = r * r, r3 = r2 * r;
         coef[row] = gm * r;                                       // P1
         coef[rows + row] = -gm * r2 * t;                          // P2
-        coef[2 * rows + row] = -gm * r * ub + gm * r2 * t * mean; // P3
+        coef[2 * rows + row] = -gm * r * ub;                      // P3 (centred form: P2, Q3 multiply x - mean)
         coef[3 * rows + row] = -r2 * s;                           // Q1
         coef[4 * rows + row] = -r2 * t * gm;                      // Q2
         coef[5 * rows + row] = -r3 * w;                           // Q3
-        coef[6 * rows + row] = r2 * (s * ub + t * ab) + r3 * w * mean; // Q4
+        coef[6 * rows + row] = r2 * (s * ub + t * ab);            // Q4
         coef[7 * rows + row] = ub;
         coef[8 * rows + row] = t;
     }
@@ -354,6 +355,7 @@ __global__ void norm_bwdbwd_ggamma_kernel(const float* __restrict__ sums, const 
 // g_gy = act'(y) * (P1*u + P2*x + P3) ;  g_x = Q1*u + Q2*gy*act'(y) + Q3*x + Q4
 __global__ __launch_bounds__(256) void norm_bwdbwd_apply_kernel(const float* __restrict__ u, const float* __restrict__ gy,
                                                                 const float* __restrict__ y, const float* __restrict__ x,
+                                                                const float* __restrict__ mean_row,
                                                                 const float* __restrict__ coef, int rows,
                                                                 long long total, int len, int vec, int act, float slope,
                                                                 float* __restrict__ g_gy, float* __restrict__ g_x)
@@ -366,7 +368,9 @@ __global__ __launch_bounds__(256) void norm_bwdbwd_apply_kernel(const float* __r
         const float Q1 = coef[3 * rows + row], Q2 = coef[4 * rows + row], Q3 = coef[5 * rows + row], Q4 = coef[6 * rows + row];
         const float4 uv = reinterpret_cast<const float4*>(u)[i];
         const float4 gv = reinterpret_cast<const float4*>(gy)[i];
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float mu = mean_row[row];
+        xv.x -= mu; xv.y -= mu; xv.z -= mu; xv.w -= mu;
         float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
         if (act != SEMPYR_ACT_NONE) {
             const float4 yv = reinterpret_cast<const float4*>(y)[i];
@@ -384,8 +388,9 @@ __global__ __launch_bounds__(256) void norm_bwdbwd_apply_kernel(const float* __r
         if (i >= total) return;
         const int row = (int)(i / len);
         const float d = act != SEMPYR_ACT_NONE ? act_deriv(y[i], act, slope) : 1.f;
-        g_gy[i] = d * (coef[row] * u[i] + coef[rows + row] * x[i] + coef[2 * rows + row]);
-        g_x[i] = coef[3 * rows + row] * u[i] + coef[4 * rows + row] * gy[i] * d + coef[5 * rows + row] * x[i] + coef[6 * rows + row];
+        const float xc = x[i] - mean_row[row];
+        g_gy[i] = d * (coef[row] * u[i] + coef[rows + row] * xc + coef[2 * rows + row]);
+        g_x[i] = coef[3 * rows + row] * u[i] + coef[4 * rows + row] * gy[i] * d + coef[5 * rows + row] * xc + coef[6 * rows + row];
     }
 }
 
@@ -457,7 +462,7 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     SEMPYR_CHECK_LAUNCH();
     const long long total = (long long)rows * HW;
     const long long nthr = vec ? total / 4 : total;
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, gy, y, x, cA, cB, cC, total, HW, vec, act, slope, gx);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, gy, y, x, mean_row, cA, cB, cC, total, HW, vec, act, slope, gx);
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }
@@ -487,7 +492,7 @@ extern "C" int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, co
     }
     const long long total = (long long)rows * HW;
     const long long nthr = vec ? total / 4 : total;
-    hipLaunchKernelGGL(norm_bwdbwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, u, gy, y, x, coef, rows, total, HW, vec, act, slope, g_gy, g_x);
+    hipLaunchKernelGGL(norm_bwdbwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, u, gy, y, x, mean_row, coef, rows, total, HW, vec, act, slope, g_gy, g_x);
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }

@@ -353,8 +353,8 @@ class _NormAct(Function):
                                   _p(rm), _p(rv), _p(nbt), momentum, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
               "sempyr_norm_stats")
         y = torch.empty_like(x)
-        check(L.sempyr_affine_act(x.data_ptr(), rowbuf.data_ptr() + 8 * rows, rowbuf.data_ptr() + 12 * rows, 0,
-                                  y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
+        check(L.sempyr_affine_act(x.data_ptr(), rowbuf.data_ptr(), rowbuf.data_ptr() + 8 * rows, rowbuf.data_ptr() + 12 * rows,
+                                  0, y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
         ctx.save_for_backward(x, y if act_kind != ACT_NONE else None, gamma, rowbuf)
         ctx.cfg = (kind, act_kind, slope)
         return y
@@ -436,7 +436,7 @@ class _AffineRowAct(Function):
         N, C, HW = _nchw(x)
         rows = N * C
         y = torch.empty_like(x)
-        check(L.sempyr_affine_act(x.data_ptr(), coeffs.data_ptr(), coeffs.data_ptr() + 4 * rows, _p(res), y.data_ptr(),
+        check(L.sempyr_affine_act(x.data_ptr(), 0, coeffs.data_ptr(), coeffs.data_ptr() + 4 * rows, _p(res), y.data_ptr(),
                                   rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
         ctx.save_for_backward(y if act_kind != ACT_NONE else None, coeffs)
         ctx.cfg = (act_kind, slope, res is not None)
@@ -480,7 +480,7 @@ def bn_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, res=None, a
 # ------------------------------------------------------------------------------------------------
 def _act_raw(x, res, act_kind, slope):
     y = torch.empty_like(x)
-    check(L.sempyr_affine_act(x.data_ptr(), 0, 0, _p(res), y.data_ptr(), 1, x.numel(), act_kind, slope, _stream()),
+    check(L.sempyr_affine_act(x.data_ptr(), 0, 0, 0, _p(res), y.data_ptr(), 1, x.numel(), act_kind, slope, _stream()),
           "sempyr_affine_act")
     return y
 

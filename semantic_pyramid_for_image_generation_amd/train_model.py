@@ -73,7 +73,7 @@ class _RowNorm(torch.autograd.Function):
         rows = x.size(0)
         coef = torch.cat([g / norms, torch.zeros_like(norms)])
         out = torch.empty_like(x)
-        ops.check(ops.L.sempyr_affine_act(x.data_ptr(), coef.data_ptr(), coef.data_ptr() + 4 * rows, 0, out.data_ptr(), rows,
+        ops.check(ops.L.sempyr_affine_act(x.data_ptr(), 0, coef.data_ptr(), coef.data_ptr() + 4 * rows, 0, out.data_ptr(), rows,
                                           x.numel() // rows, ops.ACT_NONE, 0.0, ops._stream()), "sempyr_affine_act")
         return out
 

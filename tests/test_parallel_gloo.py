@@ -1,0 +1,60 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  Checks the flat-buffer gradient all-reduce (mean over ranks,
+missing grads treated as zeros) and that parameters stay identical on both ranks after an Adam step —
+the N>1 oracle of SURVEY.md §8e: N independent replicas with averaged gradients."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from semantic_pyramid_for_image_generation_amd import parallel
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    if rank == 1:                                    # diverge, then broadcast must repair it
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    parallel.broadcast_module(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(10 + rank)     # rank-distinct data
+    x = torch.randn(4, 6, generator=g)
+    h = net[1](net[0](x))
+    loss = h.pow(2).mean()                           # net[2] gets no gradient on any rank -> zero-filled
+    net.zero_grad()
+    loss.backward()
+    local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
+    parallel.sync_gradients(net)
+    synced = [p.grad.clone() for p in net.parameters()]
+    opt.step()
+    q.put((rank, [t.numpy() for t in local], [t.numpy() for t in synced], [p.detach().numpy() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, l0, s0, p0), (_, l1, s1, p1) = res
+    import numpy as np
+    for a, b, sa, sb in zip(l0, l1, s0, s1):
+        assert np.allclose(sa, (a + b) / 2, atol=1e-7) and np.array_equal(sa, sb)
+    assert any(np.abs(a - b).max() > 1e-4 for a, b in zip(l0, l1))       # the ranks really had different grads
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)                                      # replicas stay bit-identical
