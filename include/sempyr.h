@@ -123,7 +123,7 @@ int sempyr_bn_eval_coeffs(const float* gamma, const float* beta, const float* ru
                           const float* running_var, float eps, int N, int C,
                           float* scale_row, float* shift_row, void* stream);
 
-/* (gx, ggamma, gbeta) of y = act(norm(x)); y is needed only when act != NONE. scratch: 5*N*C floats.
+/* (gx, ggamma, gbeta) of y = act(norm(x)); y is needed only when act != NONE. scratch: 8*N*C floats.
  * ggamma / gbeta may be NULL. */
 int sempyr_norm_bwd(int kind, const float* gy, const float* y, const float* x, const float* gamma,
                     const float* mean_row, const float* rstd_row, int N, int C, int HW,
@@ -131,7 +131,7 @@ int sempyr_norm_bwd(int kind, const float* gy, const float* y, const float* x, c
                     float* scratch, void* stream);
 
 /* Backward of sempyr_norm_bwd's gx output: given u = dL/d(gx) returns dL/d(gy), dL/dx, dL/dgamma
- * (g_gamma may be NULL). scratch: 14*N*C floats. */
+ * (g_gamma may be NULL). scratch: 18*N*C floats. */
 int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, const float* y, const float* x,
                         const float* gamma, const float* mean_row, const float* rstd_row,
                         int N, int C, int HW, int act, float slope,

@@ -135,82 +135,96 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
     scale_row[row] = sc; shift_row[row] = beta[c] - rm[c] * sc;
 }
 
-// s1 = sum gy', s2 = sum gy' * xhat   with gy' = gy * act'(y)
+// Per-row sums for the backward, accumulated on PIVOT-SHIFTED data: with Kg = gy'[row][0],
+//   out[0] = Kg, out[1] = sum (gy'-Kg), out[2] = sum xc, out[3] = sum (gy'-Kg)*xc      (gy' = gy*act'(y), xc = x-mean_g)
+// In the WGAN-GP inner pass gy' has a mean far above its spread in some layers; summing the raw products in fp32
+// and subtracting the mean terms afterwards loses 2-4 digits (measured 2e-2 on one critic layer). The finalize kernel
+// undoes the shift in double precision.
 template <int TPR>
 __global__ __launch_bounds__(256) void norm_bwd_rowsums_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                const float* __restrict__ x,
-                                                               const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+                                                               const float* __restrict__ mean_row,
                                                                int rows, int len, int vec, int act, float slope,
-                                                               float* __restrict__ s1, float* __restrict__ s2)
+                                                               float* __restrict__ out /* [4][rows] */)
 {
-    __shared__ float sh[8];
+    __shared__ float sh[12];
     constexpr int RPB = 256 / TPR;
     const int row = blockIdx.x * RPB + threadIdx.x / TPR;
     const int t = threadIdx.x % TPR;
     const bool live = row < rows;
     const size_t base = (size_t)(live ? row : 0) * len;
-    const float mean = mean_row[live ? row : 0], rstd = rstd_row[live ? row : 0];
-    float s[2] = {0.f, 0.f};
+    const float mean = mean_row[live ? row : 0];
+    float Kg = gy[base];
+    if (act != SEMPYR_ACT_NONE) Kg *= act_deriv(y[base], act, slope);
+    float s[3] = {0.f, 0.f, 0.f};
     if (live) {
         if (vec) {
             const float4* g4 = reinterpret_cast<const float4*>(gy + base);
             const float4* x4 = reinterpret_cast<const float4*>(x + base);
             const float4* y4 = reinterpret_cast<const float4*>(y + base);
             for (int i = t; i < len / 4; i += TPR) {
-                float4 g = g4[i]; const float4 xv = x4[i];
+                float4 g = g4[i]; float4 xv = x4[i];
                 if (act != SEMPYR_ACT_NONE) {
                     const float4 yv = y4[i];
                     g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
                     g.z *= act_deriv(yv.z, act, slope); g.w *= act_deriv(yv.w, act, slope);
                 }
+                g.x -= Kg; g.y -= Kg; g.z -= Kg; g.w -= Kg;
+                xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
                 s[0] += (g.x + g.y) + (g.z + g.w);
-                s[1] += (g.x * (xv.x - mean) + g.y * (xv.y - mean)) + (g.z * (xv.z - mean) + g.w * (xv.w - mean));
+                s[1] += (xv.x + xv.y) + (xv.z + xv.w);
+                s[2] += (g.x * xv.x + g.y * xv.y) + (g.z * xv.z + g.w * xv.w);
             }
         } else {
             for (int i = t; i < len; i += TPR) {
                 float g = gy[base + i];
                 if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[base + i], act, slope);
-                s[0] += g; s[1] += g * (x[base + i] - mean);
+                g -= Kg;
+                const float xc = x[base + i] - mean;
+                s[0] += g; s[1] += xc; s[2] += g * xc;
             }
         }
     }
-    row_reduce<TPR, 2>(s, sh);
-    if (live && t == 0) { s1[row] = s[0]; s2[row] = s[1] * rstd; }
+    row_reduce<TPR, 3>(s, sh);
+    if (live && t == 0) { out[row] = Kg; out[rows + row] = s[0]; out[2 * rows + row] = s[1]; out[3 * rows + row] = s[2]; }
 }
 
-// group sums -> per-row coefficients of gx = A*gy' + Bc*x + Cc ; channel sums -> ggamma, gbeta
-__global__ void norm_bwd_finalize_kernel(int kind, const float* __restrict__ s1, const float* __restrict__ s2,
-                                         int N, int C, int len, const float* __restrict__ gamma,
-                                         const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+// group sums -> per-row coefficients of gx = cA*gy' + cB*(x - mean) + cC ; channel sums -> ggamma, gbeta (double math)
+__global__ void norm_bwd_finalize_kernel(int kind, const float* __restrict__ sums, int N, int C, int len,
+                                         const float* __restrict__ gamma, const float* __restrict__ rstd_row,
                                          float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
                                          float* __restrict__ ggamma, float* __restrict__ gbeta)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int ng = num_groups(kind, N, C);
+    const int rows = N * C;
+    auto G1 = [&](int row) { return (double)sums[row] * len + (double)sums[rows + row]; };                        // sum gy'
+    auto G2 = [&](int row) { return ((double)sums[3 * rows + row] + (double)sums[row] * (double)sums[2 * rows + row])
+                                    * (double)rstd_row[row]; };                                                 // sum gy'*xhat
     if (idx < ng) {
         int start, stride, count;
         group_rows(kind, idx, N, C, start, stride, count);
-        float SA = 0.f, SB = 0.f;
+        double SA = 0.0, SB = 0.0;
         for (int i = 0; i < count; ++i) {
             const int row = start + i * stride;
-            const float gm = gamma[row % C];
-            SA += gm * s1[row]; SB += gm * s2[row];
+            const double gm = gamma[row % C];
+            SA += gm * G1(row); SB += gm * G2(row);
         }
-        const float m = (float)count * (float)len;
-        const float abar = SA / m, s = SB / m;
+        const double m = (double)count * (double)len;
+        const double abar = SA / m, sbar = SB / m;
         for (int i = 0; i < count; ++i) {
             const int row = start + i * stride;
-            const float r = rstd_row[row];
-            cA[row] = r * gamma[row % C];
-            cB[row] = -r * r * s;
-            cC[row] = -r * abar;                       // gx = cA*gy' + cB*(x - mean) + cC
+            const double r = rstd_row[row];
+            cA[row] = (float)(r * gamma[row % C]);
+            cB[row] = (float)(-r * r * sbar);
+            cC[row] = (float)(-r * abar);
         }
     } else if (idx < ng + C) {
         const int c = idx - ng;
-        float a = 0.f, b = 0.f;
-        for (int n = 0; n < N; ++n) { a += s1[n * C + c]; b += s2[n * C + c]; }
-        if (gbeta) gbeta[c] = a;
-        if (ggamma) ggamma[c] = b;
+        double a = 0.0, b = 0.0;
+        for (int n = 0; n < N; ++n) { a += G1(n * C + c); b += G2(n * C + c); }
+        if (gbeta) gbeta[c] = (float)a;
+        if (ggamma) ggamma[c] = (float)b;
     }
 }
 
@@ -249,22 +263,26 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
 }
 
 // ---- backward of the backward ----
-// r1 = sum u, r2 = sum u*xhat, r3 = sum gy', r4 = sum gy'*xhat, r5 = sum u*gy'
+// Pivot-shifted per-row sums (Ku = u[row][0], Kg = gy'[row][0]); out layout [9][rows]:
+//   Ku, Kg, sum(u-Ku), sum(gy'-Kg), sum xc, sum(u-Ku)*xc, sum(gy'-Kg)*xc, sum(u-Ku)*(gy'-Kg), (unused)
 template <int TPR>
 __global__ __launch_bounds__(256) void norm_bwdbwd_rowsums_kernel(const float* __restrict__ u, const float* __restrict__ gy,
                                                                   const float* __restrict__ y, const float* __restrict__ x,
-                                                                  const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+                                                                  const float* __restrict__ mean_row,
                                                                   int rows, int len, int vec, int act, float slope,
-                                                                  float* __restrict__ sums /* [5][rows] */)
+                                                                  float* __restrict__ sums)
 {
-    __shared__ float sh[20];
+    __shared__ float sh[24];
     constexpr int RPB = 256 / TPR;
     const int row = blockIdx.x * RPB + threadIdx.x / TPR;
     const int t = threadIdx.x % TPR;
     const bool live = row < rows;
     const size_t base = (size_t)(live ? row : 0) * len;
-    const float mean = mean_row[live ? row : 0], rstd = rstd_row[live ? row : 0];
-    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const float mean = mean_row[live ? row : 0];
+    const float Ku = u[base];
+    float Kg = gy[base];
+    if (act != SEMPYR_ACT_NONE) Kg *= act_deriv(y[base], act, slope);
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
         if (vec) {
             const float4* u4 = reinterpret_cast<const float4*>(u + base);
@@ -272,84 +290,117 @@ __global__ __launch_bounds__(256) void norm_bwdbwd_rowsums_kernel(const float* _
             const float4* x4 = reinterpret_cast<const float4*>(x + base);
             const float4* y4 = reinterpret_cast<const float4*>(y + base);
             for (int i = t; i < len / 4; i += TPR) {
-                const float4 uv = u4[i]; float4 g = g4[i]; float4 xv = x4[i];
+                float4 uv = u4[i]; float4 g = g4[i]; float4 xv = x4[i];
                 if (act != SEMPYR_ACT_NONE) {
                     const float4 yv = y4[i];
                     g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
                     g.z *= act_deriv(yv.z, act, slope); g.w *= act_deriv(yv.w, act, slope);
                 }
+                uv.x -= Ku; uv.y -= Ku; uv.z -= Ku; uv.w -= Ku;
+                g.x -= Kg; g.y -= Kg; g.z -= Kg; g.w -= Kg;
                 xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
                 s[0] += (uv.x + uv.y) + (uv.z + uv.w);
-                s[1] += (uv.x * xv.x + uv.y * xv.y) + (uv.z * xv.z + uv.w * xv.w);
-                s[2] += (g.x + g.y) + (g.z + g.w);
-                s[3] += (g.x * xv.x + g.y * xv.y) + (g.z * xv.z + g.w * xv.w);
-                s[4] += (uv.x * g.x + uv.y * g.y) + (uv.z * g.z + uv.w * g.w);
+                s[1] += (g.x + g.y) + (g.z + g.w);
+                s[2] += (xv.x + xv.y) + (xv.z + xv.w);
+                s[3] += (uv.x * xv.x + uv.y * xv.y) + (uv.z * xv.z + uv.w * xv.w);
+                s[4] += (g.x * xv.x + g.y * xv.y) + (g.z * xv.z + g.w * xv.w);
+                s[5] += (uv.x * g.x + uv.y * g.y) + (uv.z * g.z + uv.w * g.w);
             }
         } else {
             for (int i = t; i < len; i += TPR) {
-                const float uv = u[base + i]; float g = gy[base + i]; const float xc = x[base + i] - mean;
+                const float uv = u[base + i] - Ku; float g = gy[base + i]; const float xc = x[base + i] - mean;
                 if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[base + i], act, slope);
-                s[0] += uv; s[1] += uv * xc; s[2] += g; s[3] += g * xc; s[4] += uv * g;
+                g -= Kg;
+                s[0] += uv; s[1] += g; s[2] += xc; s[3] += uv * xc; s[4] += g * xc; s[5] += uv * g;
             }
         }
     }
-    row_reduce<TPR, 5>(s, sh);
+    row_reduce<TPR, 6>(s, sh);
     if (live && t == 0) {
-        sums[row] = s[0]; sums[rows + row] = s[1] * rstd; sums[2 * rows + row] = s[2];
-        sums[3 * rows + row] = s[3] * rstd; sums[4 * rows + row] = s[4];
+        sums[row] = Ku; sums[rows + row] = Kg;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sums[(2 + i) * rows + row] = s[i];
     }
 }
 
-// coef layout [9][rows]: P1 P2 P3 Q1 Q2 Q3 Q4 ubar t
+// un-shifted row sums in double: r1 = sum u, r2 = sum u*xhat, r3 = sum gy', r4 = sum gy'*xhat, r5 = sum u*gy'
+struct RowSums { double r1, r2, r3, r4, r5; };
+__device__ __forceinline__ RowSums unshift(const float* __restrict__ sums, int rows, int row, int len, double rstd) {
+    const double Ku = sums[row], Kg = sums[rows + row];
+    const double Su = sums[2 * rows + row], Sg = sums[3 * rows + row], Sx = sums[4 * rows + row];
+    const double Sux = sums[5 * rows + row], Sgx = sums[6 * rows + row], Sug = sums[7 * rows + row];
+    RowSums o;
+    o.r1 = Ku * len + Su;
+    o.r3 = Kg * len + Sg;
+    o.r2 = (Sux + Ku * Sx) * rstd;
+    o.r4 = (Sgx + Kg * Sx) * rstd;
+    o.r5 = Sug + Ku * Sg + Kg * Su + Ku * Kg * len;
+    return o;
+}
+
+// coef layout [9][rows]: P1 P2 P3 Q1 Q2 Q3 Q4 ubar t      (double math; see the derivation in DESIGN.md)
 __global__ void norm_bwdbwd_finalize_kernel(int kind, const float* __restrict__ sums, int N, int C, int len,
-                                            const float* __restrict__ gamma, const float* __restrict__ mean_row,
-                                            const float* __restrict__ rstd_row, float* __restrict__ coef)
+                                            const float* __restrict__ gamma, const float* __restrict__ rstd_row,
+                                            float* __restrict__ coef)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= num_groups(kind, N, C)) return;
     const int rows = N * C;
     int start, stride, count;
     group_rows(kind, g, N, C, start, stride, count);
-    float U = 0.f, T = 0.f, SA = 0.f, SB = 0.f, UA = 0.f;
+    double U = 0, T = 0, SA = 0, SB = 0, UA = 0;
     for (int i = 0; i < count; ++i) {
         const int row = start + i * stride;
-        const float gm = gamma[row % C];
-        U += sums[row]; T += sums[rows + row];
-        SA += gm * sums[2 * rows + row]; SB += gm * sums[3 * rows + row]; UA += gm * sums[4 * rows + row];
+        const double gm = gamma[row % C];
+        const RowSums q = unshift(sums, rows, row, len, rstd_row[row]);
+        U += q.r1; T += q.r2; SA += gm * q.r3; SB += gm * q.r4; UA += gm * q.r5;
     }
-    const float m = (float)count * (float)len;
-    const float ub = U / m, t = T / m, ab = SA / m, s = SB / m, mua = UA / m;
-    const float w = mua - ub * ab - 3.f * s * t;
+    const double m = (double)count * (double)len;
+    const double ub = U / m, t = T / m, ab = SA / m, s = SB / m, mua = UA / m;
+    const double w = mua - ub * ab - 3.0 * s * t;
     for (int i = 0; i < count; ++i) {
         const int row = start + i * stride;
-        const float gm = gamma[row % C];
-        const float r = rstd_row[row];
-        const float r2 = r * r, r3 = r2 * r;
-        coef[row] = gm * r;                                       // P1
-        coef[rows + row] = -gm * r2 * t;                          // P2
-        coef[2 * rows + row] = -gm * r * ub;                      // P3 (centred form: P2, Q3 multiply x - mean)
-        coef[3 * rows + row] = -r2 * s;                           // Q1
-        coef[4 * rows + row] = -r2 * t * gm;                      // Q2
-        coef[5 * rows + row] = -r3 * w;                           // Q3
-        coef[6 * rows + row] = r2 * (s * ub + t * ab);            // Q4
-        coef[7 * rows + row] = ub;
-        coef[8 * rows + row] = t;
+        const double gm = gamma[row % C];
+        const double r = rstd_row[row];
+        const double r2 = r * r, r3 = r2 * r;
+        coef[row] = (float)(gm * r);                               // P1
+        coef[rows + row] = (float)(-gm * r2 * t);                  // P2   (multiplies x - mean)
+        coef[2 * rows + row] = (float)(-gm * r * ub);              // P3
+        coef[3 * rows + row] = (float)(-r2 * s);                   // Q1
+        coef[4 * rows + row] = (float)(-r2 * t * gm);              // Q2
+        coef[5 * rows + row] = (float)(-r3 * w);                   // Q3   (multiplies x - mean)
+        coef[6 * rows + row] = (float)(r2 * (s * ub + t * ab));    // Q4
+        coef[7 * rows + row] = (float)ub;
+        coef[8 * rows + row] = (float)t;
     }
 }
 
-__global__ void norm_bwdbwd_ggamma_kernel(const float* __restrict__ sums, const float* __restrict__ coef,
-                                          const float* __restrict__ rstd_row, int N, int C, float* __restrict__ ggamma)
+// g_gamma[c] = sum_n rstd * (sum u*gy' - ubar*sum gy' - t*sum gy'*xhat), with the group's ubar and t (double math)
+__global__ void norm_bwdbwd_ggamma_kernel(int kind, const float* __restrict__ sums, const float* __restrict__ gamma,
+                                          const float* __restrict__ rstd_row, int N, int C, int len,
+                                          float* __restrict__ ggamma)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int rows = N * C;
-    float a = 0.f;
+    double a = 0.0;
     for (int n = 0; n < N; ++n) {
         const int row = n * C + c;
-        a += rstd_row[row] * (sums[4 * rows + row] - coef[7 * rows + row] * sums[2 * rows + row]
-                              - coef[8 * rows + row] * sums[3 * rows + row]);
+        // recompute the group's means in double (groups are small: N rows, 1 row or C rows)
+        const int g = kind == SEMPYR_NORM_BATCH ? c : (kind == SEMPYR_NORM_INSTANCE ? row : n);
+        int start, stride, count;
+        group_rows(kind, g, N, C, start, stride, count);
+        double U = 0, T = 0;
+        for (int i = 0; i < count; ++i) {
+            const int rr = start + i * stride;
+            const RowSums q = unshift(sums, rows, rr, len, rstd_row[rr]);
+            U += q.r1; T += q.r2;
+        }
+        const double m = (double)count * (double)len;
+        const RowSums q = unshift(sums, rows, row, len, rstd_row[row]);
+        a += (double)rstd_row[row] * (q.r5 - (U / m) * q.r3 - (T / m) * q.r4);
     }
-    ggamma[c] = a;
+    ggamma[c] = (float)a;
 }
 
 // g_gy = act'(y) * (P1*u + P2*x + P3) ;  g_x = Q1*u + Q2*gy*act'(y) + Q3*x + Q4
@@ -451,14 +502,14 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     hipStream_t st = (hipStream_t)stream;
     const int rows = N * C;
     const int vec = (HW % 4 == 0) && aligned16(gy) && aligned16(x) && aligned16(gx) && (act == SEMPYR_ACT_NONE || aligned16(y));
-    float* s1 = scratch; float* s2 = scratch + rows;
-    float* cA = scratch + 2 * rows; float* cB = scratch + 3 * rows; float* cC = scratch + 4 * rows;
-    if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, s1, s2);
-    else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, s1, s2);
+    float* sums = scratch;
+    float* cA = scratch + 4 * rows; float* cB = scratch + 5 * rows; float* cC = scratch + 6 * rows;
+    if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+    else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     SEMPYR_CHECK_LAUNCH();
     const int nthreads = num_groups(kind, N, C) + C;
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(nthreads, 64)), dim3(64), 0, st, kind, s1, s2, N, C, HW, gamma,
-                       mean_row, rstd_row, cA, cB, cC, ggamma, gbeta);
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(nthreads, 64)), dim3(64), 0, st, kind, sums, N, C, HW, gamma,
+                       rstd_row, cA, cB, cC, ggamma, gbeta);
     SEMPYR_CHECK_LAUNCH();
     const long long total = (long long)rows * HW;
     const long long nthr = vec ? total / 4 : total;
@@ -479,15 +530,15 @@ extern "C" int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, co
     const int rows = N * C;
     const int vec = (HW % 4 == 0) && aligned16(u) && aligned16(gy) && aligned16(x) && aligned16(g_gy) && aligned16(g_x) &&
                     (act == SEMPYR_ACT_NONE || aligned16(y));
-    float* sums = scratch; float* coef = scratch + 5 * rows;
-    if (HW >= 2048) hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, u, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, sums);
-    else hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, u, gy, y, x, mean_row, rstd_row, rows, HW, vec, act, slope, sums);
+    float* sums = scratch; float* coef = scratch + 9 * rows;
+    if (HW >= 2048) hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+    else hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     SEMPYR_CHECK_LAUNCH();
     hipLaunchKernelGGL(norm_bwdbwd_finalize_kernel, dim3(ceil_div(num_groups(kind, N, C), 64)), dim3(64), 0, st, kind, sums, N, C, HW,
-                       gamma, mean_row, rstd_row, coef);
+                       gamma, rstd_row, coef);
     SEMPYR_CHECK_LAUNCH();
     if (g_gamma) {
-        hipLaunchKernelGGL(norm_bwdbwd_ggamma_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, sums, coef, rstd_row, N, C, g_gamma);
+        hipLaunchKernelGGL(norm_bwdbwd_ggamma_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, kind, sums, gamma, rstd_row, N, C, HW, g_gamma);
         SEMPYR_CHECK_LAUNCH();
     }
     const long long total = (long long)rows * HW;

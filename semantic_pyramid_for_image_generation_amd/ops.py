@@ -381,7 +381,7 @@ class _NormActBwd(Function):
         want_param = not _INPUT_GRADS_ONLY
         gg = torch.empty(C, dtype=torch.float32, device=x.device) if want_param else None
         gb = torch.empty(C, dtype=torch.float32, device=x.device) if want_param else None
-        scratch = torch.empty(5 * rows, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(8 * rows, dtype=torch.float32, device=x.device)
         check(L.sempyr_norm_bwd(kind, gy.data_ptr(), _p(y), x.data_ptr(), gamma.data_ptr(), rowbuf.data_ptr(),
                                 rowbuf.data_ptr() + 4 * rows, N, C, HW, act_kind, slope, gx.data_ptr(), _p(gg), _p(gb),
                                 scratch.data_ptr(), _stream()), "sempyr_norm_bwd")
@@ -410,7 +410,7 @@ class _NormActBwd(Function):
         g_x = torch.empty_like(x)
         want_param = ctx.needs_input_grad[3] and not _INPUT_GRADS_ONLY
         g_gamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param else None
-        scratch = torch.empty(14 * rows, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(18 * rows, dtype=torch.float32, device=x.device)
         check(L.sempyr_norm_bwd_bwd(kind, u.data_ptr(), gy.data_ptr(), _p(y), x.data_ptr(), gamma.data_ptr(),
                                     rowbuf.data_ptr(), rowbuf.data_ptr() + 4 * rows, N, C, HW, act_kind, slope,
                                     g_gy.data_ptr(), g_x.data_ptr(), _p(g_gamma), scratch.data_ptr(), _stream()),

