@@ -63,6 +63,10 @@ struct IgemmParams {
     int OSY, OSX, OPY, OPX;
     int ldc;               // WGRAD slab row length
     int nchunks, chunks_per_split, nsplits;
+    // stride phases of a DGRAD fused into one launch (nphases == 1 otherwise): per-phase overrides of A/ktab/N/K-chunks/
+    // pixel grid/output offset
+    int nphases;
+    struct Phase { long long a_off; int tab_off, N, nchunks, QW, QHW, OPY, OPX; } ph[4];
     long long slab_stride; // elements between split slabs
 };
 
@@ -92,6 +96,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     //    spread over all XCDs.  (With few tiles and the split in blockIdx.y, whole XCDs would receive no work.)
     const int MT = (p.Mpad + BM - 1) / BM;
     int id = blockIdx.x, split = 0;
+    // per-launch or per-phase geometry
+    const float* pA = p.A; const int2* pktab = p.ktab;
+    int pN = p.N, pnchunks = p.nchunks, pcps = p.chunks_per_split, pQW = p.QW, pQHW = p.QHW, pOPY = p.OPY, pOPX = p.OPX;
+    if constexpr (MODE == MODE_GATHER) {
+        if (p.nphases > 1) {
+            const int phase = id % p.nphases; id /= p.nphases;
+            pA += p.ph[phase].a_off; pktab += p.ph[phase].tab_off;
+            pN = p.ph[phase].N; pnchunks = p.ph[phase].nchunks; pQW = p.ph[phase].QW; pQHW = p.ph[phase].QHW;
+            pOPY = p.ph[phase].OPY; pOPX = p.ph[phase].OPX;
+            pcps = (pnchunks + p.nsplits - 1) / p.nsplits;
+        }
+    }
     int m_tile, n_tile;
     if (p.nsplits > 1) {
         split = id % p.nsplits; id /= p.nsplits;
@@ -101,10 +117,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         n_tile = ((id >> 3) / MT) * 8 + (id & 7);
     }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
-    if (n0 >= p.N) return;                                   // uniform for the whole workgroup
+    if (n0 >= pN) return;                                   // uniform for the whole workgroup
 
-    const int c_begin = split * p.chunks_per_split;
-    const int c_end = min(c_begin + p.chunks_per_split, p.nchunks);
+    const int c_begin = split * pcps;
+    const int c_end = min(c_begin + pcps, pnchunks);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -135,12 +151,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         const int n_local = tid % BN;
         g_krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
         const int n = n0 + n_local;
-        const bool valid = n < p.N;
+        const bool valid = n < pN;
         const int nn = valid ? n : 0;
-        const int b = nn / p.QHW;
-        const int r = nn - b * p.QHW;
-        const int qy = r / p.QW;
-        const int qx = r - qy * p.QW;
+        const int b = nn / pQHW;
+        const int r = nn - b * pQHW;
+        const int qy = r / pQW;
+        const int qx = r - qy * pQW;
         g_ybase = valid ? qy * p.SY : -(1 << 20);               // invalid column never passes the bound test
         g_xbase = qx * p.SX;
         g_off = b * p.XCHW;
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #pragma unroll
         for (int i = 0; i < NTAB; ++i) {
             const int n = UT ? (n0 + w_c0 * WB_PER) : (n0 + w_c0 + 16 * i);
-            w_tab[i] = (n < p.N) ? p.ktab[n] : make_int2(0, (int)0x80008000);  // dy=dx=-32768: always out of range
+            w_tab[i] = (n < pN) ? pktab[n] : make_int2(0, (int)0x80008000);  // dy=dx=-32768: always out of range
         }
     }
 
@@ -168,12 +184,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                     const int row = idx / (BM / 4);
                     const int c4 = idx % (BM / 4);
                     const int m = m0 + c4 * 4;
-                    if (m < p.Mpad) v = *reinterpret_cast<const float4*>(p.A + (size_t)(k0 + row) * p.Mpad + m);
+                    if (m < p.Mpad) v = *reinterpret_cast<const float4*>(pA + (size_t)(k0 + row) * p.Mpad + m);
                 }
                 ra[i * 4 + 0] = v.x; ra[i * 4 + 1] = v.y; ra[i * 4 + 2] = v.z; ra[i * 4 + 3] = v.w;
             }
             if constexpr (UT) {
-                const int2 e0 = p.ktab[k0];                        // uniform: the whole chunk is one tap
+                const int2 e0 = pktab[k0];                        // uniform: the whole chunk is one tap
                 const int iy = g_ybase + (e0.y >> 16);
                 const int ix = g_xbase + (int)(short)(e0.y & 0xffff);
                 const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 const int sp = ok ? g_off + (iy >> p.ups) * p.XW + (ix >> p.ups) : 0;
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
-                    const int ch = p.ktab[k0 + g_krow0 + i * KSTEP].x;   // wave-uniform -> scalar load, scalar base
+                    const int ch = pktab[k0 + g_krow0 + i * KSTEP].x;   // wave-uniform -> scalar load, scalar base
                     rb[i] = (p.X + ch)[sp];
                 }
                 ok_b = ok ? 0xffffffffu : 0u;
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 unsigned okb = 0u;
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
-                    const int2 e = p.ktab[k0 + g_krow0 + i * KSTEP];
+                    const int2 e = pktab[k0 + g_krow0 + i * KSTEP];
                     const int iy = g_ybase + (e.y >> 16);
                     const int ix = g_xbase + (int)(short)(e.y & 0xffff);
                     const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
@@ -205,9 +221,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             const bool kv = k < p.K;
             const uint32_t kk = kv ? (uint32_t)k : 0u;
             const uint32_t b = p.dQHW.div(kk);
-            const uint32_t r = kk - b * (uint32_t)p.QHW;
+            const uint32_t r = kk - b * (uint32_t)pQHW;
             const uint32_t qy = p.dQW.div(r);
-            const uint32_t qx = r - qy * (uint32_t)p.QW;
+            const uint32_t qx = r - qy * (uint32_t)pQW;
             const int ybase = kv ? (int)qy * p.SY : -(1 << 20);
             const int xbase = (int)qx * p.SX;
             const int xoff = (int)b * p.XCHW;
@@ -215,11 +231,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             if constexpr (UT) {
                 // A: gy[b][m][r], rows m = mrow0 + i
                 const int mrow0 = m0 + w_c0 * WA_PER;
-                const int a_off = ((int)b * p.M + mrow0) * p.QHW + (int)r;
+                const int a_off = ((int)b * p.M + mrow0) * pQHW + (int)r;
 #pragma unroll
                 for (int i = 0; i < WA_PER; ++i) {
                     const bool ok = kv && (mrow0 + i) < p.M;
-                    ra[i] = p.A[ok ? a_off + i * p.QHW : 0];
+                    ra[i] = pA[ok ? a_off + i * pQHW : 0];
                     oka |= (ok ? 1u : 0u) << i;
                 }
                 // B: x[b][ci0 + i][pixel shifted by this thread's tap]
@@ -232,12 +248,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 for (int i = 0; i < WB_PER; ++i) rb[i] = (p.X + i * p.XHW)[sp];   // uniform base + one vgpr offset
                 ok_b = ok ? 0xffffffffu : 0u;
             } else {
-                const float* ap = p.A + (size_t)b * p.M * p.QHW + r;
+                const float* ap = pA + (size_t)b * p.M * pQHW + r;
 #pragma unroll
                 for (int i = 0; i < WA_PER; ++i) {
                     const int m = m0 + w_c0 + 16 * i;
                     const bool ok = kv && m < p.M;
-                    ra[i] = ap[ok ? (size_t)m * p.QHW : 0];
+                    ra[i] = ap[ok ? (size_t)m * pQHW : 0];
                     oka |= (ok ? 1u : 0u) << i;
                 }
                 unsigned okb = 0u;
@@ -295,6 +311,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         for (int c = c_begin; c < c_end; ++c) {
             const int buf = (c - c_begin) & 1;
             const bool more = (c + 1) < c_end;
+            // Nothing is in flight here (store_tiles consumed every load before the barrier). Saying so explicitly stops
+            // hipcc from guarding the loop-carried staging registers with conservative vmcnt waits BETWEEN this chunk's
+            // loads, which made the gather loads wait for the weight-tile load that had just been issued.
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) only
             if (more) load_tiles(c + 1);                       // global loads in flight under the MFMAs
             __builtin_amdgcn_sched_barrier(0);
             const float* as = As + buf * A_ELEMS + kh * LDA + wm * (TM * 32) + l31;
@@ -342,12 +362,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-            if (n >= p.N) continue;
-            const int b = n / p.QHW;
-            const int r = n - b * p.QHW;
-            const int qy = r / p.QW;
-            const int qx = r - qy * p.QW;
-            float* op = out + (size_t)b * p.OCHW + (qy * p.OSY + p.OPY) * p.OW + qx * p.OSX + p.OPX;
+            if (n >= pN) continue;
+            const int b = n / pQHW;
+            const int r = n - b * pQHW;
+            const int qy = r / pQW;
+            const int qx = r - qy * pQW;
+            float* op = out + (size_t)b * p.OCHW + (qy * p.OSY + pOPY) * p.OW + qx * p.OSX + pOPX;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-            if (n >= p.N) continue;
+            if (n >= pN) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
@@ -386,6 +406,82 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             }
         }
     }
+}
+
+// GATHER-mode convolution with at most 4 output rows (RGB image heads: generator last conv, critic/classifier stem
+// input gradients).  Padding M = 3 to a 32-row MFMA tile wastes 10x the matrix work, so this shape runs on the vector ALU:
+// one output pixel per lane (64 consecutive pixels per wave -> 256-byte coalesced gathers), weights and k-table entries
+// are wave-uniform scalar loads, 4 accumulators per lane.  HBM/L1-bound: each input element is read once per tap.
+template <bool UT>
+__global__ __launch_bounds__(256) void gather_small_m_kernel(const IgemmParams p)
+{
+    int id = blockIdx.x;
+    const float* pA = p.A; const int2* pktab = p.ktab;
+    int pN = p.N, pnchunks = p.nchunks, pQW = p.QW, pQHW = p.QHW, pOPY = p.OPY, pOPX = p.OPX;
+    if (p.nphases > 1) {
+        const int phase = id % p.nphases; id /= p.nphases;
+        pA += p.ph[phase].a_off; pktab += p.ph[phase].tab_off;
+        pN = p.ph[phase].N; pnchunks = p.ph[phase].nchunks; pQW = p.ph[phase].QW; pQHW = p.ph[phase].QHW;
+        pOPY = p.ph[phase].OPY; pOPX = p.ph[phase].OPX;
+    }
+    if (id * 256 >= pN) return;
+    const int n = id * 256 + threadIdx.x;
+    const bool valid = n < pN;
+    const int nn = valid ? n : 0;
+    const int b = nn / pQHW;
+    const int r = nn - b * pQHW;
+    const int qy = r / pQW;
+    const int qx = r - qy * pQW;
+    const int ybase = valid ? qy * p.SY : -(1 << 20);
+    const int xbase = qx * p.SX;
+    const int xoff = b * p.XCHW;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    constexpr int KS = 8;                                  // reduction indices per inner step (SGPR budget: 16 + 32)
+    for (int k0 = 0; k0 < pnchunks * BK; k0 += KS) {
+        // wave-uniform table entries and weights first, as one batch of scalar loads (a scalar load per element
+        // interleaved with the vector loads would serialise the loop on scalar-memory latency)
+        int2 ent[KS];
+        float4 w[KS];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) ent[i] = pktab[k0 + i];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) w[i] = *reinterpret_cast<const float4*>(pA + (size_t)(k0 + i) * p.Mpad);
+        __builtin_amdgcn_sched_barrier(0);
+        float xv[KS];
+        if constexpr (UT) {
+            const int iy = ybase + (ent[0].y >> 16);            // KS divides the tap's channel run: one tap per step
+            const int ix = xbase + (int)(short)(ent[0].y & 0xffff);
+            const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+            const int sp = ok ? xoff + (iy >> p.ups) * p.XW + (ix >> p.ups) : 0;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) xv[i] = (p.X + ent[i].x)[sp];
+#pragma unroll
+            for (int i = 0; i < KS; ++i) xv[i] = ok ? xv[i] : 0.f;
+        } else {
+            unsigned okb = 0u;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const int iy = ybase + (ent[i].y >> 16);
+                const int ix = xbase + (int)(short)(ent[i].y & 0xffff);
+                const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+                const int off = xoff + ent[i].x + (iy >> p.ups) * p.XW + (ix >> p.ups);
+                xv[i] = p.X[ok ? off : 0];
+                okb |= (ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < KS; ++i) xv[i] = ((okb >> i) & 1u) ? xv[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            acc0 += xv[i] * w[i].x; acc1 += xv[i] * w[i].y; acc2 += xv[i] * w[i].z; acc3 += xv[i] * w[i].w;
+        }
+    }
+    if (!valid) return;
+    float* op = p.Out + (size_t)b * p.OCHW + (qy * p.OSY + pOPY) * p.OW + qx * p.OSX + pOPX;
+    const float a[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (m < p.M) op[(size_t)m * p.OHW] = a[m] + (p.bias ? p.bias[m] : 0.f);
 }
 
 // out[i] = sum_s slab[s][i] (+ bias[channel(i)])      -- GATHER-mode split-K combine
@@ -422,21 +518,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_tail_kernel(const float* __
     out[i] = a;
 }
 
-// gw[co][ci][tap] = sum_s slab[s][co][n = tap*Cin + ci]   -- WGRAD combine + re-layout to torch order
+// gw[co][ci][tap] = sum_s slab[s][co][n = tap*Cin + ci]   -- WGRAD combine + re-layout to torch order.
+// Threads walk the slab layout (n fastest) so the `splits` reads are coalesced; the single write is the scattered one.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
                                                            int splits, long long slab_stride, int M, int Cin, int T, int ldc)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;        // index in torch layout
-    const int CT = Cin * T;
-    if (i >= M * CT) return;
-    const int m = i / CT;
-    const int r = i - m * CT;
-    const int ci = r / T;
-    const int tap = r - ci * T;
-    const size_t src = (size_t)m * ldc + tap * Cin + ci;
-    float a = slabs[src];
-    for (int k = 1; k < splits; ++k) a += slabs[(size_t)k * slab_stride + src];
-    gw[i] = a;
+    const int N = Cin * T;
+    const int i = blockIdx.x * 256 + threadIdx.x;        // index in GEMM layout: m * N + n
+    if (i >= M * N) return;
+    const int m = i / N;
+    const int n = i - m * N;
+    const int tap = n / Cin;
+    const int ci = n - tap * Cin;
+    const size_t src = (size_t)m * ldc + n;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;        // 4 interleaved partial sums (fixed order -> deterministic)
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+        a0 += slabs[(size_t)k * slab_stride + src];
+        a1 += slabs[(size_t)(k + 1) * slab_stride + src];
+        a2 += slabs[(size_t)(k + 2) * slab_stride + src];
+        a3 += slabs[(size_t)(k + 3) * slab_stride + src];
+    }
+    for (; k < splits; ++k) a0 += slabs[(size_t)k * slab_stride + src];
+    gw[(size_t)m * N + ci * T + tap] = (a0 + a1) + (a2 + a3);
 }
 
 // wp[k][m] = w[wsrc[k] + m*mstride]  (0 where wsrc[k] < 0 or m >= M)
@@ -472,14 +576,17 @@ inline int pick_cfg_wgrad(int Mpad, int Nn) {
     return pick_cfg(Mpad);
 }
 
-constexpr int TARGET_BLOCKS = 512;     // 2 workgroups per CU
-constexpr int MIN_CHUNKS_PER_SPLIT = 4;
+// split-K policy: aim at TARGET_BLOCKS workgroups (2 per CU) but keep at least MIN_CHUNKS k-chunks per split so the
+// per-workgroup prologue / slab write does not dominate. (SEMPYR_TARGET_BLOCKS / SEMPYR_MIN_CHUNKS override: tuning aid.)
+inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+inline int target_blocks() { static const int v = env_int("SEMPYR_TARGET_BLOCKS", 512); return v; }
+inline int min_chunks() { static const int v = env_int("SEMPYR_MIN_CHUNKS", 4); return v; }
 
 inline void pick_splits(int tiles, int nchunks, int& splits, int& cps) {
     splits = 1;
-    if (tiles < TARGET_BLOCKS) {
-        splits = (TARGET_BLOCKS + tiles - 1) / tiles;
-        const int maxs = nchunks / MIN_CHUNKS_PER_SPLIT > 0 ? nchunks / MIN_CHUNKS_PER_SPLIT : 1;
+    if (tiles < target_blocks()) {
+        splits = (target_blocks() + tiles - 1) / tiles;
+        const int maxs = nchunks / min_chunks() > 0 ? nchunks / min_chunks() : 1;
         if (splits > maxs) splits = maxs;
         if (splits > 512) splits = 512;
     }
@@ -533,16 +640,26 @@ template <int BM, int BN, int WM, int WN, int MODE, bool UT>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
     const int MT = (p.Mpad + BM - 1) / BM;
     const int NT = (p.N + BN - 1) / BN;
-    const int NT8 = (NT + 7) / 8 * 8;
-    dim3 grid(splits > 1 ? MT * NT * splits : MT * NT8, 1, 1);
     IgemmParams pp = p; pp.nsplits = splits;
+    if (pp.nphases < 1) pp.nphases = 1;
+    int NTm = NT; double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+    if (pp.nphases > 1) {
+        NTm = 0; flops = 0.0;
+        for (int i = 0; i < pp.nphases; ++i) {
+            const int nt = (pp.ph[i].N + BN - 1) / BN;
+            if (nt > NTm) NTm = nt;
+            flops += 2.0 * (double)p.M * (double)pp.ph[i].N * (double)pp.ph[i].nchunks * BK;
+        }
+    }
+    const int NT8m = (NTm + 7) / 8 * 8;
+    dim3 grid((splits > 1 ? MT * NTm * splits : MT * NT8m) * pp.nphases, 1, 1);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) {
         std::lock_guard<std::mutex> lk(g_prof.mu);
         if (g_prof.used + 2 <= g_prof.events.size()) {
             e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
             g_prof.used += 2;
-            g_prof.flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+            g_prof.flops += flops;
             g_prof.recs.push_back({MODE + (UT ? 0 : 2), BM, BN, p.M, p.N, p.K, splits});
         }
     }
@@ -563,8 +680,39 @@ int launch_cfg_ut(int cfg, const IgemmParams& p, int splits, hipStream_t st) {
     }
 }
 // `uniform_tap`: the gathered tensor's channel count is a multiple of BK and K needs no padding (see the kernel)
+int launch_small_m(const IgemmParams& p, bool uniform_tap, hipStream_t st) {
+    IgemmParams pp = p; pp.nsplits = 1;
+    if (pp.nphases < 1) pp.nphases = 1;
+    int maxN = p.N; double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+    if (pp.nphases > 1) {
+        maxN = 0; flops = 0.0;
+        for (int i = 0; i < pp.nphases; ++i) {
+            if (pp.ph[i].N > maxN) maxN = pp.ph[i].N;
+            flops += 2.0 * (double)p.M * (double)pp.ph[i].N * (double)pp.ph[i].nchunks * BK;
+        }
+    }
+    dim3 grid(ceil_div(maxN, 256) * pp.nphases, 1, 1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_prof.on) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.used + 2 <= g_prof.events.size()) {
+            e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
+            g_prof.used += 2;
+            g_prof.flops += flops;
+            g_prof.recs.push_back({4 + (uniform_tap ? 0 : 2), 4, 256, p.M, p.N, p.K, 1});
+        }
+    }
+    if (e0) (void)hipEventRecord(e0, st);
+    if (uniform_tap) hipLaunchKernelGGL(gather_small_m_kernel<true>, grid, dim3(256), 0, st, pp);
+    else hipLaunchKernelGGL(gather_small_m_kernel<false>, grid, dim3(256), 0, st, pp);
+    if (e1) (void)hipEventRecord(e1, st);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int MODE>
 int launch_cfg(int cfg, const IgemmParams& p, int splits, bool uniform_tap, hipStream_t st) {
+    if (MODE == MODE_GATHER && p.M <= 4 && splits == 1) return launch_small_m(p, uniform_tap, st);
     return uniform_tap ? launch_cfg_ut<MODE, true>(cfg, p, splits, st) : launch_cfg_ut<MODE, false>(cfg, p, splits, st);
 }
 
@@ -765,27 +913,41 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
         hipError_t e = hipMemsetAsync(target, 0, (size_t)(splits > 1 ? splits : 1) * in_numel * 4, st);
         if (e != hipSuccess) { sempyr_set_error("conv dgrad: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
+    // all stride phases in ONE launch (they share M, the weight layout and the split count)
+    IgemmParams p{};
+    p.A = wp; p.X = gy; p.ktab = reinterpret_cast<const int2*>(ktab);
+    p.M = d->Cin; p.Mpad = pl.Mpad;
+    p.XCHW = d->Cout * pl.Ho * pl.Wo; p.XW = pl.Wo; p.XHW = pl.Ho * pl.Wo; p.GH = pl.Ho; p.GW = pl.Wo; p.ups = 0;
+    p.SY = p.SX = 1;
+    p.OCHW = d->Cin * GH * GW; p.OHW = GH * GW; p.OW = GW;
+    p.OSY = p.OSX = s;
+    p.Out = target; p.bias = splits == 1 ? bias : nullptr; p.slab_stride = splits > 1 ? in_numel : 0;
+    p.nphases = pl.nphases;
+    int live = 0;
     for (int py = 0; py < s; ++py) for (int px = 0; px < s; ++px) {
         const int ph = py * s + px;
-        if (pl.K[ph] == 0) continue;
         const int QH = (GH - py + s - 1) / s, QW = (GW - px + s - 1) / s;
-        if (QH <= 0 || QW <= 0) continue;
-        IgemmParams p{};
-        p.A = wp + (size_t)pl.tab_off[ph] * pl.Mpad;
-        p.X = gy; p.ktab = reinterpret_cast<const int2*>(ktab) + pl.tab_off[ph];
-        p.M = d->Cin; p.Mpad = pl.Mpad; p.N = d->B * QH * QW; p.K = pl.K[ph]; p.Kpad = pl.Kpad[ph];
-        p.XCHW = d->Cout * pl.Ho * pl.Wo; p.XW = pl.Wo; p.XHW = pl.Ho * pl.Wo; p.GH = pl.Ho; p.GW = pl.Wo; p.ups = 0;
-        p.SY = p.SX = 1;
-        p.QH = QH; p.QW = QW; p.QHW = QH * QW; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
-        p.OCHW = d->Cin * GH * GW; p.OHW = GH * GW; p.OW = GW;
-        p.OSY = p.OSX = s; p.OPY = py; p.OPX = px;
-        p.nchunks = pl.Kpad[ph] / BK;
-        // all phases share the slab count so one combine pass covers the whole tensor
-        int ph_splits = splits > p.nchunks ? p.nchunks : splits;
-        p.chunks_per_split = ceil_div(p.nchunks, ph_splits);
-        ph_splits = splits;                                         // surplus splits write zeros
-        p.Out = target; p.bias = splits == 1 ? bias : nullptr; p.slab_stride = splits > 1 ? in_numel : 0;
-        if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, ph_splits, d->Cout % BK == 0, st)) return rc;
+        IgemmParams::Phase& q = p.ph[ph];
+        q.a_off = (long long)pl.tab_off[ph] * pl.Mpad;
+        q.tab_off = pl.tab_off[ph];
+        q.N = (pl.K[ph] == 0 || QH <= 0 || QW <= 0) ? 0 : d->B * QH * QW;     // N = 0: the phase's workgroups exit at once
+        q.nchunks = pl.Kpad[ph] / BK;
+        q.QW = QW > 0 ? QW : 1; q.QHW = (QH > 0 && QW > 0) ? QH * QW : 1;
+        q.OPY = py; q.OPX = px;
+        if (q.N > 0) {
+            ++live;
+            // phase 0 fields double as the single-phase view (and as the record for the profiler)
+            if (live == 1 || q.N > p.N) { p.N = q.N; p.K = pl.K[ph]; p.Kpad = pl.Kpad[ph]; }
+        }
+    }
+    if (live > 0) {
+        if (p.nphases == 1) {                                      // stride 1: plain single-phase launch
+            p.A = wp + p.ph[0].a_off; p.ktab += p.ph[0].tab_off;
+            p.N = p.ph[0].N; p.nchunks = p.ph[0].nchunks; p.QW = p.ph[0].QW; p.QHW = p.ph[0].QHW;
+            p.QH = p.QHW / p.QW; p.OPY = 0; p.OPX = 0;
+            p.chunks_per_split = ceil_div(p.nchunks, splits);
+        }
+        if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cout % BK == 0, st)) return rc;
     }
     if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, st);
     return 0;

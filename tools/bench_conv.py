@@ -7,6 +7,20 @@ from semantic_pyramid_for_image_generation_amd._lib import CONV_FWD, CONV_DGRAD,
 
 dev = torch.device('cuda:0')
 # (name, B, Cin, H, W, Cout, k, s, p, ups)
+SMALL = [
+    ('D.b3 128->256 4x4s2 @32', 16, 128, 32, 32, 256, 4, 2, 1, 0),
+    ('D.b4 256->512 4x4s2 @16', 16, 256, 16, 16, 512, 4, 2, 1, 0),
+    ('D.b5 512->512 4x4s2 @8', 16, 512, 8, 8, 512, 4, 2, 1, 0),
+    ('D.last 512->1 4x4 @4', 16, 512, 4, 4, 1, 4, 1, 0, 0),
+    ('G.c2 512->512 4x4s2 (convT) @8', 16, 512, 8, 8, 512, 4, 2, 1, 0),
+    ('G.b3 512->256 3x3 ups @8', 16, 512, 8, 8, 256, 3, 1, 1, 1),
+    ('G.b3b 256->256 3x3 @16', 16, 256, 16, 16, 256, 3, 1, 1, 0),
+    ('G.b4 256->128 3x3 ups @16', 16, 256, 16, 16, 128, 3, 1, 1, 1),
+    ('G.b5 128->64 3x3 ups @32', 16, 128, 32, 32, 64, 3, 1, 1, 1),
+    ('C.l4 512->512 3x3 @8', 16, 512, 8, 8, 512, 3, 1, 1, 0),
+    ('C.l3 256->256 3x3 @16', 16, 256, 16, 16, 256, 3, 1, 1, 0),
+    ('C.l2 128->128 3x3 @32', 16, 128, 32, 32, 128, 3, 1, 1, 0),
+]
 SHAPES = [
     ('G.b7.conv2 64->64 3x3 @256', 16, 64, 256, 256, 64, 3, 1, 1, 0),
     ('G.b7.conv1 64->64 3x3 ups @128', 16, 64, 128, 128, 64, 3, 1, 1, 1),
@@ -34,7 +48,8 @@ def timeit(fn, reps=5):
 
 
 print('%-34s %8s %8s %8s   (ms / TFLOP/s)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
-for name, B, Cin, H, W, Cout, k, s, p, ups in SHAPES:
+import sys
+for name, B, Cin, H, W, Cout, k, s, p, ups in (SMALL if 'small' in sys.argv else SHAPES):
     plan = ops.get_plan((B, Cin, H, W, Cout, k, k, s, p, ups), dev)
     x = torch.randn(B, Cin, H, W, device=dev)
     w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
