@@ -82,9 +82,11 @@ int sempyr_conv2d_tables(const sempyr_conv_desc* d, int mode, int32_t* ktab_host
 int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, const float* w,
                                const int32_t* wsrc_dev, float* wpacked, void* stream);
 
-/* y[B,Cout,Ho,Wo] = conv(x, w) (+ bias[Cout] if bias != NULL). */
+/* y[B,Cout,Ho,Wo] = act(conv(x, w) (+ bias[Cout] if bias != NULL)); act is a SEMPYR_ACT_* code applied in the
+ * kernel epilogue (`conv -> LeakyReLU` of the critic stem discriminator.py:106-107, `conv -> Tanh` of the generator head
+ * generator.py:116-120), slope the LeakyReLU slope. */
 int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wpacked_fwd,
-                      const int32_t* ktab_fwd_dev, const float* bias, float* y,
+                      const int32_t* ktab_fwd_dev, const float* bias, int act, float slope, float* y,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a

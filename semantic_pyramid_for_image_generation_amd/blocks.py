@@ -28,14 +28,16 @@ def _single(v):
     return v[0] if isinstance(v, (tuple, list)) else v
 
 
-def run_conv(layer, x, upsample=False):
-    """Execute an nn.Conv2d / nn.ConvTranspose2d container on the HIP implicit-GEMM path."""
+def run_conv(layer, x, upsample=False, act_kind=ops.ACT_NONE, slope=0.0):
+    """Execute an nn.Conv2d / nn.ConvTranspose2d container on the HIP implicit-GEMM path; an activation that
+    directly follows a Conv2d runs in the kernel epilogue."""
     stride, pad = _single(layer.stride), _single(layer.padding)
     if isinstance(layer, nn.ConvTranspose2d):
         if upsample:
             raise ValueError("fused upsample is only defined for Conv2d")
-        return ops.conv_transpose2d(x, layer.weight, layer.bias, stride, pad)
-    return ops.conv2d(x, layer.weight, layer.bias, stride, pad, upsample=upsample)
+        y = ops.conv_transpose2d(x, layer.weight, layer.bias, stride, pad)
+        return ops.act(y, act_kind, slope) if act_kind != ops.ACT_NONE else y
+    return ops.conv2d(x, layer.weight, layer.bias, stride, pad, upsample=upsample, act_kind=act_kind, slope=slope)
 
 
 def run_norm(layer, x, act_kind=ops.ACT_NONE, slope=0.0, res=None):

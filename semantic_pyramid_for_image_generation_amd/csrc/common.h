@@ -31,3 +31,21 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     __syncthreads();
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
+
+// activation of the fused epilogues / elementwise passes and its derivative expressed through the OUTPUT y
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case SEMPYR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SEMPYR_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case SEMPYR_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+__device__ __forceinline__ float act_deriv_y(float y, int act, float slope) {
+    switch (act) {
+        case SEMPYR_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case SEMPYR_ACT_LRELU: return y > 0.f ? 1.f : slope;
+        case SEMPYR_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}

@@ -68,6 +68,8 @@ struct IgemmParams {
     int nphases;
     struct Phase { long long a_off; int tab_off, N, nchunks, QW, QHW, OPY, OPX; } ph[4];
     long long slab_stride; // elements between split slabs
+    int C;                 // channel count of the gathered tensor
+    int act; float slope;  // GATHER epilogue activation (applied with the bias, only when splits == 1)
 };
 
 // UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
@@ -359,6 +361,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                     for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] += bv[r16];
             }
         }
+        if (p.act != SEMPYR_ACT_NONE) {                          // uniform
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] = act_apply(acc[i][j][r16], p.act, p.slope);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (TN * 32) + j * 32 + l31;
@@ -481,13 +491,107 @@ __global__ __launch_bounds__(256) void gather_small_m_kernel(const IgemmParams p
     const float a[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-        if (m < p.M) op[(size_t)m * p.OHW] = a[m] + (p.bias ? p.bias[m] : 0.f);
+        if (m < p.M) op[(size_t)m * p.OHW] = act_apply(a[m] + (p.bias ? p.bias[m] : 0.f), p.act, p.slope);
+}
+
+// 3x3 / stride 1 / pad 1 convolution with at most 4 output rows on the vector ALU (generator image head
+// generator.py:116, and the input gradient of the critic's 3x3 stem discriminator.py:95): 4 consecutive pixels per
+// lane, so a channel costs 3 rows x (one float4 + the two edge pixels) = 9 loads for 108 FMAs; the 9 taps of a channel
+// re-read the same three image rows back to back (L1 hits).  Weights sit in LDS as [channel][tap slot] float4 (uniform
+// address -> broadcast reads); the slot of a reduction index comes from the gather table, so FWD and DGRAD (flipped
+// taps) share the kernel.  The next channel's pixels are in flight while the current one is accumulated.
+template <int NM>
+__global__ __launch_bounds__(256) void rgb3x3_kernel(const IgemmParams p)
+{
+    extern __shared__ float4 wl[];
+    const int C = p.C;
+    for (int k = threadIdx.x; k < 9 * C; k += 256) {
+        const int tap = k / C, ci = k - tap * C;
+        const int2 e = p.ktab[k];
+        const int dy = e.y >> 16, dx = (int)(short)(e.y & 0xffff);
+        wl[ci * 9 + (dy + 1) * 3 + (dx + 1)] = *reinterpret_cast<const float4*>(p.A + (size_t)k * p.Mpad);
+    }
+    __syncthreads();
+    const int W = p.GW, H = p.GH, W4 = W >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;              // pixel quad
+    const bool valid = q < (p.N >> 2);
+    const int qq = valid ? q : 0;
+    const int per_img = H * W4;
+    const int b = qq / per_img;
+    const int r = qq - b * per_img;
+    const int y = r / W4;
+    const int x0 = (r - y * W4) * 4;
+    const float* xb = p.X + (size_t)b * p.XCHW;
+    int ro[3]; bool rok[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int yy = y + d - 1;
+        rok[d] = (unsigned)yy < (unsigned)H;
+        ro[d] = (rok[d] ? yy : y) * W + x0;                    // out-of-image rows read row y and are zeroed below
+    }
+    const bool lok = x0 > 0, rrok = x0 + 4 < W;
+    const int xl = lok ? -1 : 0, xr = rrok ? 4 : 0;
+    float acc[NM][4];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+
+    struct Stage { float4 c[3]; float l[3], r[3]; };
+    auto load = [&](Stage& s, int ci) {
+        const float* pl = xb + (size_t)ci * p.XHW;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            s.c[d] = *reinterpret_cast<const float4*>(pl + ro[d]);
+            s.l[d] = pl[ro[d] + xl];
+            s.r[d] = pl[ro[d] + xr];
+        }
+    };
+    auto compute = [&](const Stage& s, int ci) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float v[6];
+            v[0] = (rok[d] && lok) ? s.l[d] : 0.f;
+            v[1] = rok[d] ? s.c[d].x : 0.f; v[2] = rok[d] ? s.c[d].y : 0.f;
+            v[3] = rok[d] ? s.c[d].z : 0.f; v[4] = rok[d] ? s.c[d].w : 0.f;
+            v[5] = (rok[d] && rrok) ? s.r[d] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float4 w4 = wl[ci * 9 + d * 3 + t];
+                const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][j] += w[m] * v[j + t];
+            }
+        }
+    };
+    Stage sa, sb;
+    load(sa, 0);
+    for (int ci = 0; ci < C; ci += 2) {
+        load(sb, min(ci + 1, C - 1));
+        compute(sa, ci);
+        load(sa, min(ci + 2, C - 1));
+        if (ci + 1 < C) compute(sb, ci + 1);
+    }
+    if (!valid) return;
+    float* op = p.Out + (size_t)b * p.OCHW + y * W + x0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        if (m < p.M) {
+            const float bv = p.bias ? p.bias[m] : 0.f;
+            *reinterpret_cast<float4*>(op + (size_t)m * p.OHW) =
+                make_float4(act_apply(acc[m][0] + bv, p.act, p.slope), act_apply(acc[m][1] + bv, p.act, p.slope),
+                            act_apply(acc[m][2] + bv, p.act, p.slope), act_apply(acc[m][3] + bv, p.act, p.slope));
+        }
+    }
 }
 
 // out[i] = sum_s slab[s][i] (+ bias[channel(i)])      -- GATHER-mode split-K combine
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                             const float* __restrict__ bias, int splits,
-                                                            long long slab_stride, int total4, int OHW, int OC)
+                                                            long long slab_stride, int total4, int OHW, int OC,
+                                                            int act, float slope)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
@@ -503,19 +607,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         a.x += bias[(e / OHW) % OC]; a.y += bias[((e + 1) / OHW) % OC];
         a.z += bias[((e + 2) / OHW) % OC]; a.w += bias[((e + 3) / OHW) % OC];
     }
+    if (act != SEMPYR_ACT_NONE) {
+        a.x = act_apply(a.x, act, slope); a.y = act_apply(a.y, act, slope);
+        a.z = act_apply(a.z, act, slope); a.w = act_apply(a.w, act, slope);
+    }
     reinterpret_cast<float4*>(out)[i] = a;
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_tail_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                  const float* __restrict__ bias, int splits,
-                                                                 long long slab_stride, int begin, int total, int OHW, int OC)
+                                                                 long long slab_stride, int begin, int total, int OHW, int OC,
+                                                                 int act, float slope)
 {
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     float a = slabs[i];
     for (int k = 1; k < splits; ++k) a += slabs[(size_t)k * slab_stride + i];
     if (bias) a += bias[(i / OHW) % OC];
-    out[i] = a;
+    out[i] = act_apply(a, act, slope);
 }
 
 // gw[co][ci][tap] = sum_s slab[s][co][n = tap*Cin + ci]   -- WGRAD combine + re-layout to torch order.
@@ -629,7 +738,7 @@ struct Profiler {
     std::mutex mu;
     bool on = false;
     std::vector<hipEvent_t> events;     // pairs (start, stop)
-    struct Rec { int mode, bm, bn, M, N, K, splits; };
+    struct Rec { int mode, bm, bn, M, N, K, splits, nphases; double flops; };
     std::vector<Rec> recs;
     size_t used = 0;
     double flops = 0.0;
@@ -660,7 +769,7 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
             e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
             g_prof.used += 2;
             g_prof.flops += flops;
-            g_prof.recs.push_back({MODE + (UT ? 0 : 2), BM, BN, p.M, p.N, p.K, splits});
+            g_prof.recs.push_back({MODE + (UT ? 0 : 2), BM, BN, p.M, p.N, p.K, splits, pp.nphases, flops});
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
@@ -699,12 +808,43 @@ int launch_small_m(const IgemmParams& p, bool uniform_tap, hipStream_t st) {
             e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
             g_prof.used += 2;
             g_prof.flops += flops;
-            g_prof.recs.push_back({4 + (uniform_tap ? 0 : 2), 4, 256, p.M, p.N, p.K, 1});
+            g_prof.recs.push_back({4 + (uniform_tap ? 0 : 2), 4, 256, p.M, p.N, p.K, 1, pp.nphases, flops});
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
     if (uniform_tap) hipLaunchKernelGGL(gather_small_m_kernel<true>, grid, dim3(256), 0, st, pp);
     else hipLaunchKernelGGL(gather_small_m_kernel<false>, grid, dim3(256), 0, st, pp);
+    if (e1) (void)hipEventRecord(e1, st);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Shapes served by rgb3x3_kernel: 3x3 / stride 1 / pad 1, no fused upsample, <= 4 GEMM rows, image width % 4 == 0.
+inline bool rgb3x3_ok(const sempyr_conv_desc* d, int mode) {
+    const int M = mode == SEMPYR_CONV_FWD ? d->Cout : d->Cin;
+    const int C = mode == SEMPYR_CONV_FWD ? d->Cin : d->Cout;
+    return (mode == SEMPYR_CONV_FWD || mode == SEMPYR_CONV_DGRAD) && M <= 4 && C <= 256 && d->kh == 3 && d->kw == 3 &&
+           d->stride == 1 && d->pad == 1 && d->ups == 0 && d->Win % 4 == 0;
+}
+
+int launch_rgb3x3(const IgemmParams& p, hipStream_t st) {
+    if (((uintptr_t)p.X | (uintptr_t)p.Out) & 15) SEMPYR_FAIL("conv: rgb3x3 path needs 16-byte aligned tensors");
+    dim3 grid(ceil_div(p.N / 4, 256), 1, 1);
+    const size_t lds = (size_t)9 * p.C * sizeof(float4);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_prof.on) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.used + 2 <= g_prof.events.size()) {
+            e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
+            g_prof.used += 2;
+            const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+            g_prof.flops += flops;
+            g_prof.recs.push_back({8, 4, 1024, p.M, p.N, p.K, 1, 1, flops});
+        }
+    }
+    if (e0) (void)hipEventRecord(e0, st);
+    if (p.M <= 3) hipLaunchKernelGGL(rgb3x3_kernel<3>, grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(rgb3x3_kernel<4>, grid, dim3(256), lds, st, p);
     if (e1) (void)hipEventRecord(e1, st);
     SEMPYR_CHECK_LAUNCH();
     return 0;
@@ -739,6 +879,7 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         const long long N = (long long)d->B * g.Ho * g.Wo;
         int cps;
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn), plan->Kpad[0] / BK, plan->splits[0], cps);
+        if (rgb3x3_ok(d, mode) && N >= 4096) plan->splits[0] = 1;
         plan->workspace_bytes = plan->splits[0] > 1 ? (long long)plan->splits[0] * out_numel * 4 : 0;
     } else if (mode == SEMPYR_CONV_DGRAD) {
         const int s = d->stride;
@@ -757,8 +898,10 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
             const int QH = (g.GHin - py + s - 1) / s, QW = (g.GWin - px + s - 1) / s;
             const long long N = (long long)d->B * QH * QW;
             int cps; plan->splits[ph] = 1;
+            // the s*s phases run as one launch: count the workgroups of all of them against the target
             if (plan->K[ph] > 0 && N > 0)
-                pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn), plan->Kpad[ph] / BK, plan->splits[ph], cps);
+                pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn) * s * s, plan->Kpad[ph] / BK, plan->splits[ph], cps);
+            if (rgb3x3_ok(d, mode) && N >= 4096) plan->splits[ph] = 1;
             if (plan->splits[ph] > max_splits) max_splits = plan->splits[ph];
         }
         plan->tab_entries = off;
@@ -845,28 +988,29 @@ extern "C" int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, c
 }
 
 static int run_splitk_reduce(const float* slabs, float* out, const float* bias, int splits, long long numel,
-                             int OHW, int OC, hipStream_t st)
+                             int OHW, int OC, int act, float slope, hipStream_t st)
 {
     // float4 path only when every slab start (k * numel floats) stays 16-byte aligned
     if (numel % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0) {
         const int total4 = (int)(numel / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st,
-                           slabs, out, bias, splits, numel, total4, OHW, OC);
+                           slabs, out, bias, splits, numel, total4, OHW, OC, act, slope);
     } else {
         hipLaunchKernelGGL(splitk_reduce_tail_kernel, dim3(ceil_div(numel, 256)), dim3(256), 0, st,
-                           slabs, out, bias, splits, numel, 0, (int)numel, OHW, OC);
+                           slabs, out, bias, splits, numel, 0, (int)numel, OHW, OC, act, slope);
     }
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
-                                 const int32_t* ktab, const float* bias, float* y,
+                                 const int32_t* ktab, const float* bias, int act, float slope, float* y,
                                  void* ws, size_t ws_bytes, void* stream)
 {
     sempyr_conv_plan pl;
     if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_FWD, &pl)) return rc;
     if (!x || !wp || !ktab || !y) SEMPYR_FAIL("conv fwd: null pointer");
+    if (act < SEMPYR_ACT_NONE || act > SEMPYR_ACT_TANH) SEMPYR_FAIL("conv fwd: bad activation %d", act);
     if ((size_t)pl.workspace_bytes > ws_bytes || (pl.workspace_bytes && !ws))
         SEMPYR_FAIL("conv fwd: workspace too small (%zu < %lld)", ws_bytes, (long long)pl.workspace_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -883,10 +1027,12 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     p.nchunks = pl.Kpad[0] / BK;
     const int splits = pl.splits[0];
     p.chunks_per_split = ceil_div(p.nchunks, splits);
-    if (splits == 1) { p.Out = y; p.bias = bias; p.slab_stride = 0; }
+    p.C = d->Cin;
+    if (splits == 1) { p.Out = y; p.bias = bias; p.slab_stride = 0; p.act = act; p.slope = slope; }
     else { p.Out = (float*)ws; p.bias = nullptr; p.slab_stride = out_numel; }
+    if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) return launch_rgb3x3(p, st);
     if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
-    if (splits > 1) return run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, st);
+    if (splits > 1) return run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st);
     return 0;
 }
 
@@ -947,9 +1093,11 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
             p.QH = p.QHW / p.QW; p.OPY = 0; p.OPX = 0;
             p.chunks_per_split = ceil_div(p.nchunks, splits);
         }
+        p.C = d->Cout;
+        if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_DGRAD)) return launch_rgb3x3(p, st);
         if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cout % BK == 0, st)) return rc;
     }
-    if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, st);
+    if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, SEMPYR_ACT_NONE, 0.f, st);
     return 0;
 }
 
@@ -1009,7 +1157,7 @@ extern "C" int sempyr_profile_end(double* kernel_ms, int64_t* launches, double* 
     double ms = 0.0;
     const char* dump = getenv("SEMPYR_PROFILE_DUMP");      // optional per-launch CSV (tuning aid)
     FILE* df = dump ? fopen(dump, "w") : nullptr;
-    if (df) fprintf(df, "mode,bm,bn,M,N,K,splits,ms\n");
+    if (df) fprintf(df, "mode,bm,bn,M,N,K,splits,nphases,gflop,ms\n");
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         hipError_t rc = hipEventSynchronize(g_prof.events[i + 1]);
         if (rc != hipSuccess) { sempyr_set_error("profile_end: hipEventSynchronize: %s", hipGetErrorString(rc)); return (int)rc; }
@@ -1019,7 +1167,7 @@ extern "C" int sempyr_profile_end(double* kernel_ms, int64_t* launches, double* 
         ms += t;
         if (df && i / 2 < g_prof.recs.size()) {
             const Profiler::Rec& r = g_prof.recs[i / 2];
-            fprintf(df, "%d,%d,%d,%d,%d,%d,%d,%.5f\n", r.mode, r.bm, r.bn, r.M, r.N, r.K, r.splits, t);
+            fprintf(df, "%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.5f\n", r.mode, r.bm, r.bn, r.M, r.N, r.K, r.splits, r.nphases, r.flops * 1e-9, t);
         }
     }
     if (df) fclose(df);

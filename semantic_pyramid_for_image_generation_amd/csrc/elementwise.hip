@@ -10,23 +10,6 @@ namespace {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-__device__ __forceinline__ float act_apply(float v, int act, float slope) {
-    switch (act) {
-        case SEMPYR_ACT_RELU: return v > 0.f ? v : 0.f;
-        case SEMPYR_ACT_LRELU: return v > 0.f ? v : v * slope;
-        case SEMPYR_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
-}
-__device__ __forceinline__ float act_deriv_y(float y, int act, float slope) {
-    switch (act) {
-        case SEMPYR_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        case SEMPYR_ACT_LRELU: return y > 0.f ? 1.f : slope;
-        case SEMPYR_ACT_TANH: return 1.f - y * y;
-        default: return 1.f;
-    }
-}
-
 // y = act((x - sub[row]) * scale[row] + shift[row] + res)      (sub optional)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sub,
                                                          const float* __restrict__ scale,

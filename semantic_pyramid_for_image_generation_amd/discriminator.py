@@ -103,8 +103,7 @@ class Discriminator(nn.Module):
         self.last_conv = nn.Conv2d(512, 1, 4, stride=1, padding=0)    # -> 1
 
     def forward(self, x):
-        x = run_conv(self.first_conv, x)
-        x = ops.act(x, ops.ACT_LRELU, float(self.leaky_relu.negative_slope))
+        x = run_conv(self.first_conv, x, act_kind=ops.ACT_LRELU, slope=float(self.leaky_relu.negative_slope))
         if self.dis_type == 'res':
             x = ops.avg_pool2(x)
         for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5):

@@ -106,8 +106,7 @@ class Generator(nn.Module):
             x = block(x, ops.mul(features[level], masks[level]))
         if self.gen_type == 'res':
             x = self.conv_block7(x)
-        x = run_conv(self.last_conv, x)
-        return ops.act(x, ops.ACT_TANH)
+        return run_conv(self.last_conv, x, act_kind=ops.ACT_TANH)
 
     def init_weights(self):
         blocks = [self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5,

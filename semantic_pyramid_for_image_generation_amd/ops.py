@@ -161,13 +161,13 @@ def _workspace(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-def _raw_conv_fwd(plan, x, w, bias):
+def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0):
     mp = plan.mode(CONV_FWD)
     wp = _packed_weights(plan, w, CONV_FWD)
     y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device)
     ws = _workspace(mp.ws_bytes, x.device)
-    check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(), _p(bias), y.data_ptr(),
-                              _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
+    check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(), _p(bias), act_kind, slope,
+                              y.data_ptr(), _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
     return y
 
 
@@ -208,23 +208,27 @@ def _bias_grad(g):
 
 
 class _ConvFwd(Function):
-    """y = conv2d(x[, upsampled x2], w) + bias."""
+    """y = act(conv2d(x[, upsampled x2], w) + bias); the activation runs in the kernel epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, plan):
+    def forward(ctx, x, w, bias, plan, act_kind=ACT_NONE, slope=0.0):
         x = _req(x, "conv input"); w = _req(w, "conv weight")
         if bias is not None:
             bias = _req(bias, "conv bias")
-        ctx.save_for_backward(x, w)
+        y = _raw_conv_fwd(plan, x, w, bias, act_kind, slope)
+        ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None)
         ctx.plan = plan
         ctx.has_bias = bias is not None
-        return _raw_conv_fwd(plan, x, w, bias)
+        ctx.act = (act_kind, slope)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         plan = ctx.plan
         gy = gy.contiguous()
+        if y is not None:
+            gy = _ActBwd.apply(gy, y, *ctx.act)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(gy, w, plan)
@@ -233,7 +237,7 @@ class _ConvFwd(Function):
                 gw = _ConvWgrad.apply(gy, x, plan)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = _bias_grad(gy)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None, None
 
 
 def _conv_input_grad(gy, w, plan):
@@ -296,15 +300,16 @@ class _ConvWgrad(Function):
         return g_gy, g_x, None
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False):
+def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NONE, slope=0.0):
     """nn.Conv2d forward (reference generator.py:25, discriminator.py:37), optionally reading its input
-    through a fused nn.UpsamplingNearest2d(2) (generator.py:44,78)."""
+    through a fused nn.UpsamplingNearest2d(2) (generator.py:44,78) and applying a following activation
+    (discriminator.py:106-107, generator.py:116-120) in the kernel epilogue."""
     B, Cin, H, W = x.shape
     Cout, Cin_w, kh, kw = w.shape
     if Cin_w != Cin:
         raise _lib.SempyrError(f"conv2d: weight expects {Cin_w} input channels, got {Cin}")
     plan = get_plan((B, Cin, H, W, Cout, kh, kw, stride, padding, 1 if upsample else 0), x.device)
-    return _ConvFwd.apply(x, w, bias, plan)
+    return _ConvFwd.apply(x, w, bias, plan, act_kind, slope)
 
 
 def conv_transpose2d(x, w, bias=None, stride=1, padding=0):

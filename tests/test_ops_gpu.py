@@ -34,6 +34,10 @@ CONV_CASES = [
     (1, 5, 9, 11, 7, 3, 1, 1, 0, True),         # ragged everything
     (2, 96, 6, 6, 96, 3, 1, 1, 0, False),       # Mpad = 96 -> 32-wide tiles
     (1, 512, 8, 8, 512, 3, 1, 1, 0, False),     # deep K, split-K path
+    (2, 64, 64, 64, 3, 3, 1, 1, 0, True),       # G last conv, large enough for the 4-pixels-per-lane VALU kernel
+    (2, 3, 64, 64, 64, 3, 1, 1, 0, True),       # D stem (res): its input gradient runs on the same kernel
+    (1, 5, 64, 68, 3, 3, 1, 1, 0, True),        # odd channel count, non-square image
+    (1, 6, 64, 64, 4, 3, 1, 1, 0, False),       # 4 output rows
 ]
 
 
@@ -63,6 +67,33 @@ def test_conv2d_fwd_bwd(dev, case):
     assert rel_err(wd.grad, wr.grad) < tol
     if has_bias:
         assert rel_err(bd.grad, br.grad) < tol
+
+
+# (case, activation): the epilogue activation on the single-pass MFMA path, the split-K combine and the VALU head
+@pytest.mark.parametrize("case", [(2, 3, 32, 32, 64, 3, 1, 1, 0, True), (1, 512, 8, 8, 512, 3, 1, 1, 0, True),
+                                  (2, 64, 64, 64, 3, 3, 1, 1, 0, True), (2, 64, 32, 32, 3, 3, 1, 1, 0, True)])
+@pytest.mark.parametrize("act", ['lrelu', 'tanh'])
+def test_conv2d_fused_activation(dev, case, act):
+    ops = _ops()
+    B, Cin, H, W, Cout, k, s, p, ups, has_bias = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    pre = F.conv2d(xr, wr, br, s, p)
+    yr = F.leaky_relu(pre, 0.2) if act == 'lrelu' else torch.tanh(pre)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True); bd = b.to(dev).requires_grad_(True)
+    kind = ops.ACT_LRELU if act == 'lrelu' else ops.ACT_TANH
+    y = ops.conv2d(xd, wd, bd, s, p, act_kind=kind, slope=0.2)
+    y.backward(gy.to(dev))
+    tol = 2e-5
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+    assert rel_err(bd.grad, br.grad) < tol
 
 
 CONVT_CASES = [
@@ -119,6 +150,12 @@ def test_conv_double_backward(dev):
         return gx, x.grad, w.grad
     ref = run(lambda x, w, b: F.conv2d(x, w, b, 2, 1), x, w, b)
     out = run(lambda x, w, b: ops.conv2d(x, w, b, 2, 1), x.to(dev), w.to(dev), b.to(dev), ops.input_grads_only)
+    for o, r in zip(out, ref):
+        assert rel_err(o, r) < 5e-5
+    # the same through the fused conv + LeakyReLU epilogue (critic stem)
+    ref = run(lambda x, w, b: F.leaky_relu(F.conv2d(x, w, b, 2, 1), 0.2), x, w, b)
+    out = run(lambda x, w, b: ops.conv2d(x, w, b, 2, 1, act_kind=ops.ACT_LRELU, slope=0.2), x.to(dev), w.to(dev), b.to(dev),
+              ops.input_grads_only)
     for o, r in zip(out, ref):
         assert rel_err(o, r) < 5e-5
 
