@@ -22,6 +22,12 @@
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// The gather table is read-only for the lifetime of a launch.  Reading it through the constant address space makes
+// its wave-uniform reads scalar loads; as plain global loads hipcc turns every read after the first workgroup barrier
+// into a per-lane vector load (a barrier counts as a possible clobber), i.e. a dependent memory round trip in front of
+// the gathers of every k-chunk.
+typedef const int __attribute__((address_space(4)))* ctab_ptr;
+__device__ __forceinline__ int2 ctab_get(ctab_ptr t, int k) { return make_int2(t[2 * k], t[2 * k + 1]); }
 
 namespace {
 
@@ -92,32 +98,36 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // Workgroup -> (tile, split). Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an XCD/L2):
-    //  * no split-K: the m-tiles that re-read one activation tile get ids 8 apart -> same L2;
+    // Workgroup -> (phase, tile, split). Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an XCD/L2):
+    //  * no split-K: the m-tiles that re-read one activation tile (and the stride phases of a fused DGRAD) get ids 8
+    //    apart -> same L2; consecutive n-tiles go to consecutive XCDs.  (Giving each XCD a contiguous band of pixel rows
+    //    instead was measured: 1.5% faster on the 256x256 3x3 layers, 20% slower on the store-bound 1x1 / RGB-stem ones.)
     //  * split-K: the split index is the fastest-varying part of the id, so the splits of a tile (which share nothing)
     //    spread over all XCDs.  (With few tiles and the split in blockIdx.y, whole XCDs would receive no work.)
     const int MT = (p.Mpad + BM - 1) / BM;
-    int id = blockIdx.x, split = 0;
+    int id = blockIdx.x, split = 0, phase = 0, m_tile, n_tile;
+    if (p.nsplits > 1) {
+        phase = id % p.nphases; id /= p.nphases;
+        split = id % p.nsplits; id /= p.nsplits;
+        m_tile = id % MT; n_tile = id / MT;
+    } else {
+        const int xcd = id & 7; id >>= 3;
+        phase = id % p.nphases; id /= p.nphases;
+        m_tile = id % MT;
+        n_tile = (id / MT) * 8 + xcd;
+    }
     // per-launch or per-phase geometry
     const float* pA = p.A; const int2* pktab = p.ktab;
     int pN = p.N, pnchunks = p.nchunks, pcps = p.chunks_per_split, pQW = p.QW, pQHW = p.QHW, pOPY = p.OPY, pOPX = p.OPX;
     if constexpr (MODE == MODE_GATHER) {
         if (p.nphases > 1) {
-            const int phase = id % p.nphases; id /= p.nphases;
             pA += p.ph[phase].a_off; pktab += p.ph[phase].tab_off;
             pN = p.ph[phase].N; pnchunks = p.ph[phase].nchunks; pQW = p.ph[phase].QW; pQHW = p.ph[phase].QHW;
             pOPY = p.ph[phase].OPY; pOPX = p.ph[phase].OPX;
             pcps = (pnchunks + p.nsplits - 1) / p.nsplits;
         }
     }
-    int m_tile, n_tile;
-    if (p.nsplits > 1) {
-        split = id % p.nsplits; id /= p.nsplits;
-        m_tile = id % MT; n_tile = id / MT;
-    } else {
-        m_tile = (id >> 3) % MT;
-        n_tile = ((id >> 3) / MT) * 8 + (id & 7);
-    }
+    const ctab_ptr ctab = (ctab_ptr)pktab;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     if (n0 >= pN) return;                                   // uniform for the whole workgroup
 
@@ -175,6 +185,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         }
     }
 
+    int2 e_nxt = make_int2(0, 0);      // UT GATHER: table entry of the next chunk to load, fetched one call ahead
+    if constexpr (MODE == MODE_GATHER && UT) e_nxt = ctab_get(ctab, min(c_begin, pnchunks - 1) * BK);
+
     auto load_tiles = [&](int chunk) {
         const int k0 = chunk * BK;
         if constexpr (MODE == MODE_GATHER) {
@@ -191,23 +204,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 ra[i * 4 + 0] = v.x; ra[i * 4 + 1] = v.y; ra[i * 4 + 2] = v.z; ra[i * 4 + 3] = v.w;
             }
             if constexpr (UT) {
-                const int2 e0 = pktab[k0];                        // uniform: the whole chunk is one tap
+                // uniform: the whole chunk is one tap (e0.y) and its channels are consecutive planes from e0.x
+                const int2 e0 = e_nxt;
+                e_nxt = ctab_get(ctab, min(chunk + 1, pnchunks - 1) * BK);
                 const int iy = g_ybase + (e0.y >> 16);
                 const int ix = g_xbase + (int)(short)(e0.y & 0xffff);
                 const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
                 // out-of-range pixels read offset 0 of the channel plane (always mapped) and are zeroed when staged
                 const int sp = ok ? g_off + (iy >> p.ups) * p.XW + (ix >> p.ups) : 0;
+                const float* xb = p.X + e0.x + g_krow0 * p.XHW;         // wave-uniform base
 #pragma unroll
-                for (int i = 0; i < B_PER; ++i) {
-                    const int ch = pktab[k0 + g_krow0 + i * KSTEP].x;   // wave-uniform -> scalar load, scalar base
-                    rb[i] = (p.X + ch)[sp];
-                }
+                for (int i = 0; i < B_PER; ++i) rb[i] = (xb + (size_t)(i * KSTEP) * p.XHW)[sp];
                 ok_b = ok ? 0xffffffffu : 0u;
             } else {
                 unsigned okb = 0u;
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
-                    const int2 e = pktab[k0 + g_krow0 + i * KSTEP];
+                    const int2 e = ctab_get(ctab, k0 + g_krow0 + i * KSTEP);
                     const int iy = g_ybase + (e.y >> 16);
                     const int ix = g_xbase + (int)(short)(e.y & 0xffff);
                     const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
@@ -290,9 +303,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 }
             }
             const int n_local = tid % BN;
+            if constexpr (UT) {
+                const bool okb = ok_b != 0u;
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i)
-                bs[(g_krow0 + i * KSTEP) * LDB + n_local] = ((ok_b >> i) & 1u) ? rb[i] : 0.f;
+                for (int i = 0; i < B_PER; ++i) bs[(g_krow0 + i * KSTEP) * LDB + n_local] = okb ? rb[i] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i)
+                    bs[(g_krow0 + i * KSTEP) * LDB + n_local] = ((ok_b >> i) & 1u) ? rb[i] : 0.f;
+            }
         } else {
             const int k_local = tid & 15;
 #pragma unroll
