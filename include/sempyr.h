@@ -147,6 +147,11 @@ int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, const float* 
  * 99,102) and the residual adds generator.py:56,87 ; discriminator.py:63. */
 int sempyr_affine_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
                       const float* res, float* y, int rows, int len, int act, float slope, void* stream);
+/* y = act((x-sub)*scale+shift + (res-rsub)*rscale+rshift): two normalised branches summed and activated in one pass
+ * (generator residual block: BatchNorm(conv2) + BatchNorm(skip) -> ReLU, generator.py:54-57). */
+int sempyr_affine2_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
+                       const float* res, const float* rsub_row, const float* rscale_row, const float* rshift_row,
+                       float* y, int rows, int len, int act, float slope, void* stream);
 /* g' = gy*act'(y); gx = g'*scale_row (NULL -> 1), gres = g' ; either output may be NULL. */
 int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_row, float* gx, float* gres,
                           int rows, int len, int act, float slope, void* stream);
@@ -160,10 +165,15 @@ int sempyr_lerp_rows(const float* real, const float* fake, const float* alpha_ro
 /* transforms.Normalize train_model.py:240-245 : y=(x-mean_c)/std_c ; backward!=0: y = x/std_c */
 int sempyr_normalize(const float* x, const float* mean_c, const float* std_c, float* y,
                      int N, int C, int HW, int backward, void* stream);
-/* y[r][h][w] = scale*sum 2x2 : nn.AvgPool2d(2) (scale .25) discriminator.py:57,103 ; upsample backward (scale 1) */
-int sempyr_pool2_down(const float* x, float* y, int rows, int H, int W, float scale, void* stream);
-/* y[r][2h+a][2w+b] = scale*x[r][h][w] : nn.UpsamplingNearest2d(2) generator.py:44 ; avg-pool backward (scale .25) */
-int sempyr_pool2_up(const float* x, float* y, int rows, int h, int w, float scale, void* stream);
+/* y[r][h][w] = scale*sum 2x2 : nn.AvgPool2d(2) (scale .25) discriminator.py:57,103 ; upsample backward (scale 1).
+ * yref (optional, fine resolution, output of a ReLU/LeakyReLU): every x is first multiplied by act'(yref). */
+int sempyr_pool2_down(const float* x, const float* yref, float* y, int rows, int H, int W, float scale,
+                      int act, float slope, void* stream);
+/* y[r][2h+a][2w+b] = scale*x[r][h][w] : nn.UpsamplingNearest2d(2) generator.py:44 ; avg-pool backward (scale .25).
+ * yref (optional, fine resolution): the result is multiplied by act'(yref) -- the backward of
+ * `LeakyReLU -> AvgPool2d` (discriminator.py:107-109) in one pass. */
+int sempyr_pool2_up(const float* x, const float* yref, float* y, int rows, int h, int w, float scale,
+                    int act, float slope, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the ResNet18 stem classifier.py:36 ; idx = argmax offsets for the backward */
 int sempyr_maxpool3s2_fwd(const float* x, float* y, int32_t* idx, int rows, int H, int W, void* stream);
 int sempyr_maxpool3s2_bwd(const float* gy, const int32_t* idx, float* gx, int rows, int H, int W, void* stream);

@@ -52,13 +52,14 @@ SIGNATURES = {
     "sempyr_norm_bwd": [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
     "sempyr_norm_bwd_bwd": [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
     "sempyr_affine_act": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_affine2_act": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
     "sempyr_affine_act_bwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
     "sempyr_mul": [_P, _P, _P, c_int64, _P],
     "sempyr_axpby": [_P, _P, c_float, c_float, _P, c_int64, _P],
     "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],
     "sempyr_normalize": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
-    "sempyr_pool2_down": [_P, _P, c_int, c_int, c_int, c_float, _P],
-    "sempyr_pool2_up": [_P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_pool2_down": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
+    "sempyr_pool2_up": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
     "sempyr_maxpool3s2_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "sempyr_maxpool3s2_bwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "sempyr_reduce_scratch_floats": [],

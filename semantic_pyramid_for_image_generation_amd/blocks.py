@@ -28,7 +28,7 @@ def _single(v):
     return v[0] if isinstance(v, (tuple, list)) else v
 
 
-def run_conv(layer, x, upsample=False, act_kind=ops.ACT_NONE, slope=0.0):
+def run_conv(layer, x, upsample=False, act_kind=ops.ACT_NONE, slope=0.0, pool=False):
     """Execute an nn.Conv2d / nn.ConvTranspose2d container on the HIP implicit-GEMM path; an activation that
     directly follows a Conv2d runs in the kernel epilogue."""
     stride, pad = _single(layer.stride), _single(layer.padding)
@@ -36,8 +36,9 @@ def run_conv(layer, x, upsample=False, act_kind=ops.ACT_NONE, slope=0.0):
         if upsample:
             raise ValueError("fused upsample is only defined for Conv2d")
         y = ops.conv_transpose2d(x, layer.weight, layer.bias, stride, pad)
-        return ops.act(y, act_kind, slope) if act_kind != ops.ACT_NONE else y
-    return ops.conv2d(x, layer.weight, layer.bias, stride, pad, upsample=upsample, act_kind=act_kind, slope=slope)
+        y = ops.act(y, act_kind, slope) if act_kind != ops.ACT_NONE else y
+        return ops.avg_pool2(y) if pool else y
+    return ops.conv2d(x, layer.weight, layer.bias, stride, pad, upsample=upsample, act_kind=act_kind, slope=slope, pool=pool)
 
 
 def run_norm(layer, x, act_kind=ops.ACT_NONE, slope=0.0, res=None):
@@ -71,6 +72,34 @@ def run_norm(layer, x, act_kind=ops.ACT_NONE, slope=0.0, res=None):
         raise NotImplementedError(f"no HIP kernel for {type(layer).__name__}")
     y = ops.norm_act(x, layer.weight, layer.bias, kind, act_kind if res is None else ops.ACT_NONE, slope, layer.eps)
     return ops.add_act(y, res, act_kind, slope) if res is not None else y
+
+
+def _train_norm_kind(layer):
+    """(kind, bn_state) when `layer` is a norm container that computes batch statistics right now, else None."""
+    if isinstance(layer, nn.BatchNorm2d):
+        if not (layer.training or not layer.track_running_stats):
+            return None
+        state = None
+        if layer.track_running_stats:
+            if layer.momentum is None:
+                return None
+            state = (layer.running_mean, layer.running_var, layer.num_batches_tracked, float(layer.momentum))
+        return ops.NORM_BATCH, state
+    if isinstance(layer, nn.InstanceNorm2d) and layer.affine and not layer.track_running_stats:
+        return ops.NORM_INSTANCE, None
+    if isinstance(layer, nn.GroupNorm) and layer.num_groups == 1:
+        return ops.NORM_LAYER, None
+    return None
+
+
+def run_norm_add_norm_act(norm_a, a, norm_b, b, act_kind=ops.ACT_NONE, slope=0.0):
+    """act(norm_a(a) + norm_b(b)) — the tail of a residual block.  Two training-mode norms of the same kind run as one
+    fused apply pass; anything else falls back to norm_b, then norm_a with the residual."""
+    ka, kb = _train_norm_kind(norm_a), _train_norm_kind(norm_b)
+    if ka is not None and kb is not None and ka[0] == kb[0]:
+        return ops.norm_add_norm_act(a, norm_a.weight, norm_a.bias, b, norm_b.weight, norm_b.bias, ka[0], act_kind, slope,
+                                     norm_a.eps, norm_b.eps, ka[1], kb[1])
+    return run_norm(norm_a, a, act_kind, slope, res=run_norm(norm_b, b))
 
 
 def activation_kind(layer):

@@ -10,29 +10,46 @@ namespace {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// y = act((x - sub[row]) * scale[row] + shift[row] + res)      (sub optional)
+// y = act((x - sub[row]) * scale[row] + shift[row] + R)      (sub optional)
+// R = res, or (res - rsub[row]) * rscale[row] + rshift[row] when the residual carries its own per-row affine (two norm
+// layers summed: generator.py:54-57).
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sub,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const float* __restrict__ res,
+                                                         const float* __restrict__ rsub, const float* __restrict__ rscale,
+                                                         const float* __restrict__ rshift,
                                                          float* __restrict__ y, long long total, int len, int vec,
                                                          int act, float slope)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (vec) {
         if (i * 4 >= total) return;
+        const int row = (int)((i * 4) / len);
         float sc = 1.f, sh = 0.f, mu = 0.f;
-        if (scale) { const int row = (int)((i * 4) / len); sc = scale[row]; sh = shift[row]; if (sub) mu = sub[row]; }
+        if (scale) { sc = scale[row]; sh = shift[row]; if (sub) mu = sub[row]; }
         float4 v = reinterpret_cast<const float4*>(x)[i];
         v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh; v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
-        if (res) { const float4 r = reinterpret_cast<const float4*>(res)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (res) {
+            float4 r = reinterpret_cast<const float4*>(res)[i];
+            if (rscale) {
+                const float rs = rscale[row], rh = rshift[row], rm = rsub ? rsub[row] : 0.f;
+                r.x = (r.x - rm) * rs + rh; r.y = (r.y - rm) * rs + rh; r.z = (r.z - rm) * rs + rh; r.w = (r.w - rm) * rs + rh;
+            }
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
         v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
         v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
         reinterpret_cast<float4*>(y)[i] = v;
     } else {
         if (i >= total) return;
+        const int row = (int)(i / len);
         float v = x[i];
-        if (scale) { const int row = (int)(i / len); v = (v - (sub ? sub[row] : 0.f)) * scale[row] + shift[row]; }
-        if (res) v += res[i];
+        if (scale) v = (v - (sub ? sub[row] : 0.f)) * scale[row] + shift[row];
+        if (res) {
+            float r = res[i];
+            if (rscale) r = (r - (rsub ? rsub[row] : 0.f)) * rscale[row] + rshift[row];
+            v += r;
+        }
         y[i] = act_apply(v, act, slope);
     }
 }
@@ -137,9 +154,12 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
     }
 }
 
-// y[r][h][w] = scale * sum_{a,b in 0..1} x[r][2h+a][2w+b]      (H, W even; h = H/2)
-__global__ __launch_bounds__(256) void pool2_down_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                         long long total_out, int h, int w, float scale)
+// y[r][h][w] = scale * sum_{a,b in 0..1} x[r][2h+a][2w+b] * act'(yref[r][2h+a][2w+b])      (H, W even; h = H/2)
+// yref (optional) is the OUTPUT of a sign-preserving activation at the fine resolution: with it this is the backward of
+// pool2_up_kernel's fused form below.
+__global__ __launch_bounds__(256) void pool2_down_kernel(const float* __restrict__ x, const float* __restrict__ yref,
+                                                         float* __restrict__ y, long long total_out, int h, int w,
+                                                         float scale, int act, float slope)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total_out) return;
@@ -147,15 +167,24 @@ __global__ __launch_bounds__(256) void pool2_down_kernel(const float* __restrict
     const long long t = i / w;
     const int oy = (int)(t % h);
     const long long r = t / h;
-    const float2* p0 = reinterpret_cast<const float2*>(x + (r * (2 * h) + 2 * oy) * (2 * (long long)w)) + ox;
-    const float2* p1 = p0 + w;
-    const float2 a = *p0, b = *p1;
+    const long long off = (r * (2 * h) + 2 * oy) * (2 * (long long)w);
+    const float2* p0 = reinterpret_cast<const float2*>(x + off) + ox;
+    float2 a = *p0, b = *(p0 + w);
+    if (yref) {
+        const float2* q0 = reinterpret_cast<const float2*>(yref + off) + ox;
+        const float2 ya = *q0, yb = *(q0 + w);
+        a.x *= act_deriv_y(ya.x, act, slope); a.y *= act_deriv_y(ya.y, act, slope);
+        b.x *= act_deriv_y(yb.x, act, slope); b.y *= act_deriv_y(yb.y, act, slope);
+    }
     y[i] = scale * ((a.x + a.y) + (b.x + b.y));
 }
 
-// y[r][2h+a][2w+b] = scale * x[r][h][w]
-__global__ __launch_bounds__(256) void pool2_up_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                       long long total_in, int h, int w, float scale)
+// y[r][2h+a][2w+b] = scale * x[r][h][w] * act'(yref[r][2h+a][2w+b]): nearest upsample / avg-pool backward, optionally
+// fused with the backward of the activation that fed the pool (critic stem: conv -> LeakyReLU -> AvgPool2d,
+// discriminator.py:106-109), which saves one full-resolution read+write pass.
+__global__ __launch_bounds__(256) void pool2_up_kernel(const float* __restrict__ x, const float* __restrict__ yref,
+                                                       float* __restrict__ y, long long total_in, int h, int w,
+                                                       float scale, int act, float slope)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total_in) return;
@@ -164,9 +193,17 @@ __global__ __launch_bounds__(256) void pool2_up_kernel(const float* __restrict__
     const int iy = (int)(t % h);
     const long long r = t / h;
     const float v = scale * x[i];
-    float2* p0 = reinterpret_cast<float2*>(y + (r * (2 * h) + 2 * iy) * (2 * (long long)w)) + ix;
-    *p0 = make_float2(v, v);
-    *(p0 + w) = make_float2(v, v);
+    const long long off = (r * (2 * h) + 2 * iy) * (2 * (long long)w);
+    float2 a = make_float2(v, v), b = a;
+    if (yref) {
+        const float2* q0 = reinterpret_cast<const float2*>(yref + off) + ix;
+        const float2 ya = *q0, yb = *(q0 + w);
+        a.x *= act_deriv_y(ya.x, act, slope); a.y *= act_deriv_y(ya.y, act, slope);
+        b.x *= act_deriv_y(yb.x, act, slope); b.y *= act_deriv_y(yb.y, act, slope);
+    }
+    float2* p0 = reinterpret_cast<float2*>(y + off) + ix;
+    *p0 = a;
+    *(p0 + w) = b;
 }
 
 // 3x3 stride-2 pad-1 max pool; idx = flat offset (iy*W+ix) of the first maximum in scan order
@@ -227,18 +264,36 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __rest
     hipLaunchKernelGGL(kernel, dim3(ceil_div((nthreads), 256)), dim3(256), 0, (st), __VA_ARGS__); \
     SEMPYR_CHECK_LAUNCH(); } while (0)
 
-extern "C" int sempyr_affine_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
-                                 const float* res, float* y, int rows, int len, int act, float slope, void* stream)
+static int affine_act_launch(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
+                             const float* res, const float* rsub_row, const float* rscale_row, const float* rshift_row,
+                             float* y, int rows, int len, int act, float slope, void* stream)
 {
     if (!x || !y) SEMPYR_FAIL("affine_act: null pointer");
     if ((scale_row == nullptr) != (shift_row == nullptr)) SEMPYR_FAIL("affine_act: scale and shift must both be given");
     if (sub_row && !scale_row) SEMPYR_FAIL("affine_act: sub_row needs scale/shift");
+    if ((rscale_row == nullptr) != (rshift_row == nullptr)) SEMPYR_FAIL("affine_act: residual scale and shift must both be given");
+    if ((rscale_row || rsub_row) && (!res || !rscale_row)) SEMPYR_FAIL("affine_act: residual coefficients need res, scale and shift");
     if (rows < 1 || len < 1) SEMPYR_FAIL("affine_act: bad dims");
     if (act < 0 || act > 3) SEMPYR_FAIL("affine_act: bad activation %d", act);
     const long long total = (long long)rows * len;
     const int vec = (len % 4 == 0) && aligned16(x) && aligned16(y) && (!res || aligned16(res));
-    LAUNCH_1D(affine_act_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, sub_row, scale_row, shift_row, res, y, total, len, vec, act, slope);
+    LAUNCH_1D(affine_act_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, sub_row, scale_row, shift_row, res,
+              rsub_row, rscale_row, rshift_row, y, total, len, vec, act, slope);
     return 0;
+}
+
+extern "C" int sempyr_affine_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
+                                 const float* res, float* y, int rows, int len, int act, float slope, void* stream)
+{
+    return affine_act_launch(x, sub_row, scale_row, shift_row, res, nullptr, nullptr, nullptr, y, rows, len, act, slope, stream);
+}
+
+extern "C" int sempyr_affine2_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
+                                  const float* res, const float* rsub_row, const float* rscale_row, const float* rshift_row,
+                                  float* y, int rows, int len, int act, float slope, void* stream)
+{
+    if (!res || !rscale_row) SEMPYR_FAIL("affine2_act: the residual and its coefficients are required");
+    return affine_act_launch(x, sub_row, scale_row, shift_row, res, rsub_row, rscale_row, rshift_row, y, rows, len, act, slope, stream);
 }
 
 extern "C" int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_row, float* gx, float* gres,
@@ -290,21 +345,25 @@ extern "C" int sempyr_normalize(const float* x, const float* mean_c, const float
     return 0;
 }
 
-extern "C" int sempyr_pool2_down(const float* x, float* y, int rows, int H, int W, float scale, void* stream)
+extern "C" int sempyr_pool2_down(const float* x, const float* yref, float* y, int rows, int H, int W, float scale,
+                                 int act, float slope, void* stream)
 {
     if (!x || !y || rows < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) SEMPYR_FAIL("pool2_down: bad arguments (H=%d W=%d)", H, W);
-    if (((uintptr_t)x & 7) != 0) SEMPYR_FAIL("pool2_down: input must be 8-byte aligned");
+    if ((((uintptr_t)x | (uintptr_t)yref) & 7) != 0) SEMPYR_FAIL("pool2_down: inputs must be 8-byte aligned");
+    if (act < 0 || act > 3) SEMPYR_FAIL("pool2_down: bad activation %d", act);
     const long long total = (long long)rows * (H / 2) * (W / 2);
-    LAUNCH_1D(pool2_down_kernel, total, (hipStream_t)stream, x, y, total, H / 2, W / 2, scale);
+    LAUNCH_1D(pool2_down_kernel, total, (hipStream_t)stream, x, yref, y, total, H / 2, W / 2, scale, act, slope);
     return 0;
 }
 
-extern "C" int sempyr_pool2_up(const float* x, float* y, int rows, int h, int w, float scale, void* stream)
+extern "C" int sempyr_pool2_up(const float* x, const float* yref, float* y, int rows, int h, int w, float scale,
+                               int act, float slope, void* stream)
 {
     if (!x || !y || rows < 1 || h < 1 || w < 1) SEMPYR_FAIL("pool2_up: bad arguments");
-    if (((uintptr_t)y & 7) != 0) SEMPYR_FAIL("pool2_up: output must be 8-byte aligned");
+    if ((((uintptr_t)y | (uintptr_t)yref) & 7) != 0) SEMPYR_FAIL("pool2_up: output / yref must be 8-byte aligned");
+    if (act < 0 || act > 3) SEMPYR_FAIL("pool2_up: bad activation %d", act);
     const long long total = (long long)rows * h * w;
-    LAUNCH_1D(pool2_up_kernel, total, (hipStream_t)stream, x, y, total, h, w, scale);
+    LAUNCH_1D(pool2_up_kernel, total, (hipStream_t)stream, x, yref, y, total, h, w, scale, act, slope);
     return 0;
 }
 

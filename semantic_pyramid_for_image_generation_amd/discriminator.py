@@ -103,9 +103,8 @@ class Discriminator(nn.Module):
         self.last_conv = nn.Conv2d(512, 1, 4, stride=1, padding=0)    # -> 1
 
     def forward(self, x):
-        x = run_conv(self.first_conv, x, act_kind=ops.ACT_LRELU, slope=float(self.leaky_relu.negative_slope))
-        if self.dis_type == 'res':
-            x = ops.avg_pool2(x)
+        x = run_conv(self.first_conv, x, act_kind=ops.ACT_LRELU, slope=float(self.leaky_relu.negative_slope),
+                     pool=(self.dis_type == 'res'))
         for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5):
             x = blk(x)
         return run_conv(self.last_conv, x)

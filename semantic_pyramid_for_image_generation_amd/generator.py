@@ -5,7 +5,7 @@ convolutions instead of being materialised (reference generator.py:51-52,85)."""
 import torch.nn as nn
 
 from . import ops
-from .blocks import init_weights, run_conv, run_conv_norm_act  # noqa: F401  (init_weights re-exported)
+from .blocks import init_weights, run_conv, run_conv_norm_act, run_norm_add_norm_act  # noqa: F401  (init_weights re-exported)
 
 
 class ConvBlock(nn.Module):
@@ -40,10 +40,11 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         up = self.need_upsample           # both consumers gather through the x2 upsample; no 4x tensor is written
-        residual = self.skip_block(x, upsample=up)
+        residual = run_conv(self.skip_block.block[0], x, upsample=up)
         h = self.conv_block1(x, upsample=up)
-        h = self.conv_block2(h)
-        return ops.add_act(h, residual, ops.ACT_RELU)
+        h = run_conv(self.conv_block2.block[0], h)
+        # BatchNorm(conv2) + BatchNorm(skip) -> add -> ReLU in one apply pass (both blocks have no activation of their own)
+        return run_norm_add_norm_act(self.conv_block2.block[1], h, self.skip_block.block[1], residual, ops.ACT_RELU)
 
     def init_weights(self):
         for blk in (self.conv_block1, self.conv_block2, self.skip_block):

@@ -18,7 +18,7 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, CONV_DGRAD, CONV_FWD
 
 L = _lib.lib
 
-__all__ = ["conv2d", "conv_transpose2d", "norm_act", "bn_eval_act", "act", "add_act", "mul", "normalize",
+__all__ = ["conv2d", "conv_transpose2d", "norm_act", "norm_add_norm_act", "bn_eval_act", "act", "add_act", "mul", "normalize",
            "avg_pool2", "upsample2", "max_pool3s2", "global_avg_pool", "mean", "l1_mean", "gp_loss", "lerp_rows",
            "input_grads_only", "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_TANH", "NORM_BATCH", "NORM_INSTANCE",
            "NORM_LAYER"]
@@ -208,26 +208,38 @@ def _bias_grad(g):
 
 
 class _ConvFwd(Function):
-    """y = act(conv2d(x[, upsampled x2], w) + bias); the activation runs in the kernel epilogue."""
+    """y = act(conv2d(x[, upsampled x2], w) + bias), the activation running in the kernel epilogue; with `pool`
+    the Function returns AvgPool2d(2)(y) and its backward folds the pool's and the activation's backward into one pass
+    (critic stem, discriminator.py:106-109)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, plan, act_kind=ACT_NONE, slope=0.0):
+    def forward(ctx, x, w, bias, plan, act_kind=ACT_NONE, slope=0.0, pool=False):
         x = _req(x, "conv input"); w = _req(w, "conv weight")
         if bias is not None:
             bias = _req(bias, "conv bias")
+        if act_kind == ACT_TANH and pool:
+            raise _lib.SempyrError("conv2d: pooled output needs a ReLU-family (or no) activation")
         y = _raw_conv_fwd(plan, x, w, bias, act_kind, slope)
         ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None)
         ctx.plan = plan
         ctx.has_bias = bias is not None
         ctx.act = (act_kind, slope)
-        return y
+        ctx.pool = pool
+        if not pool:
+            return y
+        out = torch.empty((plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2), dtype=torch.float32, device=x.device)
+        check(L.sempyr_pool2_down(y.data_ptr(), 0, out.data_ptr(), plan.B * plan.Cout, plan.Ho, plan.Wo, 0.25, ACT_NONE, 0.0,
+                                  _stream()), "sempyr_pool2_down")
+        return out
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         plan = ctx.plan
         gy = gy.contiguous()
-        if y is not None:
+        if ctx.pool:
+            gy = _Pool2Up.apply(gy, 0.25, y, *ctx.act)
+        elif y is not None:
             gy = _ActBwd.apply(gy, y, *ctx.act)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
@@ -237,7 +249,7 @@ class _ConvFwd(Function):
                 gw = _ConvWgrad.apply(gy, x, plan)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = _bias_grad(gy)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def _conv_input_grad(gy, w, plan):
@@ -300,16 +312,19 @@ class _ConvWgrad(Function):
         return g_gy, g_x, None
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NONE, slope=0.0):
+def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NONE, slope=0.0, pool=False):
     """nn.Conv2d forward (reference generator.py:25, discriminator.py:37), optionally reading its input
     through a fused nn.UpsamplingNearest2d(2) (generator.py:44,78) and applying a following activation
-    (discriminator.py:106-107, generator.py:116-120) in the kernel epilogue."""
+    (discriminator.py:106-107, generator.py:116-120) in the kernel epilogue.  `pool`: also apply the
+    nn.AvgPool2d(2) that follows (discriminator.py:109)."""
     B, Cin, H, W = x.shape
     Cout, Cin_w, kh, kw = w.shape
     if Cin_w != Cin:
         raise _lib.SempyrError(f"conv2d: weight expects {Cin_w} input channels, got {Cin}")
     plan = get_plan((B, Cin, H, W, Cout, kh, kw, stride, padding, 1 if upsample else 0), x.device)
-    return _ConvFwd.apply(x, w, bias, plan, act_kind, slope)
+    if pool and (plan.Ho % 2 or plan.Wo % 2):
+        raise _lib.SempyrError("conv2d: pooled output needs even output height and width")
+    return _ConvFwd.apply(x, w, bias, plan, act_kind, slope, pool)
 
 
 def conv_transpose2d(x, w, bias=None, stride=1, padding=0):
@@ -342,21 +357,29 @@ def _nchw(x):
     return N, C, x.numel() // (N * C)
 
 
+def _norm_stats(x, gamma, beta, kind, eps, bn_state):
+    """per-row (mean, rstd, scale, shift) of a training-mode norm; updates the BatchNorm running statistics."""
+    N, C, HW = _nchw(x)
+    rows = N * C
+    rowbuf = torch.empty(4 * rows, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
+    rm = rv = nbt = None
+    momentum = 0.0
+    if bn_state is not None:
+        rm, rv, nbt, momentum = bn_state
+    check(L.sempyr_norm_stats(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(),
+                              _p(rm), _p(rv), _p(nbt), momentum, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
+          "sempyr_norm_stats")
+    return rowbuf
+
+
 class _NormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, kind, act_kind, slope, eps, bn_state):
         x = _req(x, "norm input"); gamma = _req(gamma, "norm weight"); beta = _req(beta, "norm bias")
         N, C, HW = _nchw(x)
         rows = N * C
-        rowbuf = torch.empty(4 * rows, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
-        rm = rv = nbt = None
-        momentum = 0.0
-        if bn_state is not None:
-            rm, rv, nbt, momentum = bn_state
-        check(L.sempyr_norm_stats(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(),
-                                  _p(rm), _p(rv), _p(nbt), momentum, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
-              "sempyr_norm_stats")
+        rowbuf = _norm_stats(x, gamma, beta, kind, eps, bn_state)
         y = torch.empty_like(x)
         check(L.sempyr_affine_act(x.data_ptr(), rowbuf.data_ptr(), rowbuf.data_ptr() + 8 * rows, rowbuf.data_ptr() + 12 * rows,
                                   0, y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
@@ -372,6 +395,43 @@ class _NormAct(Function):
         if _INPUT_GRADS_ONLY:
             gg = gb = None
         return gx, gg, gb, None, None, None, None, None
+
+
+class _NormAddNormAct(Function):
+    """y = act(norm_a(a) + norm_b(b)): the tail of a residual block (generator.py:54-57) in one apply pass instead of
+    two norm passes and an add.  The backward is composed of the single-norm pieces."""
+
+    @staticmethod
+    def forward(ctx, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b):
+        a = _req(a, "norm input"); b = _req(b, "norm input")
+        if a.shape != b.shape:
+            raise _lib.SempyrError("norm_add_norm_act: shape mismatch")
+        gamma_a = _req(gamma_a, "norm weight"); beta_a = _req(beta_a, "norm bias")
+        gamma_b = _req(gamma_b, "norm weight"); beta_b = _req(beta_b, "norm bias")
+        N, C, HW = _nchw(a)
+        rows = N * C
+        ra = _norm_stats(a, gamma_a, beta_a, kind, eps_a, state_a)
+        rb = _norm_stats(b, gamma_b, beta_b, kind, eps_b, state_b)
+        y = torch.empty_like(a)
+        check(L.sempyr_affine2_act(a.data_ptr(), ra.data_ptr(), ra.data_ptr() + 8 * rows, ra.data_ptr() + 12 * rows,
+                                   b.data_ptr(), rb.data_ptr(), rb.data_ptr() + 8 * rows, rb.data_ptr() + 12 * rows,
+                                   y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine2_act")
+        ctx.save_for_backward(a, b, y if act_kind != ACT_NONE else None, gamma_a, gamma_b, ra, rb)
+        ctx.cfg = (kind, act_kind, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, b, y, gamma_a, gamma_b, ra, rb = ctx.saved_tensors
+        kind, act_kind, slope = ctx.cfg
+        g = gy.contiguous()
+        if y is not None:
+            g = _ActBwd.apply(g, y, act_kind, slope)
+        ga, gga, gba = _NormActBwd.apply(g, a, None, gamma_a, ra, kind, ACT_NONE, 0.0)
+        gb, ggb, gbb = _NormActBwd.apply(g, b, None, gamma_b, rb, kind, ACT_NONE, 0.0)
+        if _INPUT_GRADS_ONLY:
+            gga = gba = ggb = gbb = None
+        return ga, gga, gba, None, gb, ggb, gbb, None, None, None, None, None, None
 
 
 class _NormActBwd(Function):
@@ -428,6 +488,12 @@ def norm_act(x, gamma, beta, kind, act_kind=ACT_NONE, slope=0.0, eps=1e-5, bn_st
     LeakyReLU (reference generator.py:27-29, discriminator.py:37-39).  `bn_state` =
     (running_mean, running_var, num_batches_tracked, momentum) is updated in place for BATCH."""
     return _NormAct.apply(x, gamma, beta, kind, act_kind, slope, eps, bn_state)
+
+
+def norm_add_norm_act(a, gamma_a, beta_a, b, gamma_b, beta_b, kind, act_kind=ACT_NONE, slope=0.0, eps_a=1e-5, eps_b=1e-5,
+                      state_a=None, state_b=None):
+    """act(norm(a) + norm(b)) for two training-mode norm layers of the same kind (generator.py:54-57)."""
+    return _NormAddNormAct.apply(a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b)
 
 
 class _AffineRowAct(Function):
@@ -596,33 +662,45 @@ def normalize(x, mean_c, std_c):
 # pooling / upsampling
 # ------------------------------------------------------------------------------------------------
 class _Pool2Down(Function):
+    """y = scale * sum_2x2 (x * act'(yref)); yref = None: plain 2x2 sum."""
+
     @staticmethod
-    def forward(ctx, x, scale):
+    def forward(ctx, x, scale, yref=None, act_kind=ACT_NONE, slope=0.0):
         x = _req(x, "input")
         N, C, H, W = x.shape
         y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        check(L.sempyr_pool2_down(x.data_ptr(), y.data_ptr(), N * C, H, W, scale, _stream()), "sempyr_pool2_down")
-        ctx.scale = scale
+        check(L.sempyr_pool2_down(x.data_ptr(), _p(yref), y.data_ptr(), N * C, H, W, scale, act_kind, slope, _stream()),
+              "sempyr_pool2_down")
+        ctx.save_for_backward(yref)
+        ctx.cfg = (scale, act_kind, slope)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return _Pool2Up.apply(g.contiguous(), ctx.scale), None
+        (yref,) = ctx.saved_tensors
+        scale, act_kind, slope = ctx.cfg
+        return _Pool2Up.apply(g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
 
 
 class _Pool2Up(Function):
+    """y = scale * nearest_up2(x) * act'(yref); yref = None: plain nearest upsample."""
+
     @staticmethod
-    def forward(ctx, x, scale):
+    def forward(ctx, x, scale, yref=None, act_kind=ACT_NONE, slope=0.0):
         x = _req(x, "input")
         N, C, h, w = x.shape
         y = torch.empty((N, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-        check(L.sempyr_pool2_up(x.data_ptr(), y.data_ptr(), N * C, h, w, scale, _stream()), "sempyr_pool2_up")
-        ctx.scale = scale
+        check(L.sempyr_pool2_up(x.data_ptr(), _p(yref), y.data_ptr(), N * C, h, w, scale, act_kind, slope, _stream()),
+              "sempyr_pool2_up")
+        ctx.save_for_backward(yref)
+        ctx.cfg = (scale, act_kind, slope)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return _Pool2Down.apply(g.contiguous(), ctx.scale), None
+        (yref,) = ctx.saved_tensors
+        scale, act_kind, slope = ctx.cfg
+        return _Pool2Down.apply(g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
 
 
 def avg_pool2(x):

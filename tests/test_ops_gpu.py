@@ -72,7 +72,7 @@ def test_conv2d_fwd_bwd(dev, case):
 # (case, activation): the epilogue activation on the single-pass MFMA path, the split-K combine and the VALU head
 @pytest.mark.parametrize("case", [(2, 3, 32, 32, 64, 3, 1, 1, 0, True), (1, 512, 8, 8, 512, 3, 1, 1, 0, True),
                                   (2, 64, 64, 64, 3, 3, 1, 1, 0, True), (2, 64, 32, 32, 3, 3, 1, 1, 0, True)])
-@pytest.mark.parametrize("act", ['lrelu', 'tanh'])
+@pytest.mark.parametrize("act", ['lrelu', 'tanh', 'lrelu+pool'])
 def test_conv2d_fused_activation(dev, case, act):
     ops = _ops()
     B, Cin, H, W, Cout, k, s, p, ups, has_bias = case
@@ -82,12 +82,16 @@ def test_conv2d_fused_activation(dev, case, act):
     b = torch.randn(Cout, generator=g) * 0.1
     xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     pre = F.conv2d(xr, wr, br, s, p)
-    yr = F.leaky_relu(pre, 0.2) if act == 'lrelu' else torch.tanh(pre)
+    pool = act.endswith('+pool')
+    yr = torch.tanh(pre) if act == 'tanh' else F.leaky_relu(pre, 0.2)
+    if pool:
+        yr = F.avg_pool2d(yr, 2)
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy)
     xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True); bd = b.to(dev).requires_grad_(True)
-    kind = ops.ACT_LRELU if act == 'lrelu' else ops.ACT_TANH
-    y = ops.conv2d(xd, wd, bd, s, p, act_kind=kind, slope=0.2)
+    kind = ops.ACT_TANH if act == 'tanh' else ops.ACT_LRELU
+    y = ops.conv2d(xd, wd, bd, s, p, act_kind=kind, slope=0.2, pool=pool)
+    assert y.shape == yr.shape
     y.backward(gy.to(dev))
     tol = 2e-5
     assert rel_err(y, yr) < tol
@@ -152,10 +156,15 @@ def test_conv_double_backward(dev):
     out = run(lambda x, w, b: ops.conv2d(x, w, b, 2, 1), x.to(dev), w.to(dev), b.to(dev), ops.input_grads_only)
     for o, r in zip(out, ref):
         assert rel_err(o, r) < 5e-5
-    # the same through the fused conv + LeakyReLU epilogue (critic stem)
+    # the same through the fused conv + LeakyReLU epilogue (critic stem), without and with the fused AvgPool2d(2)
     ref = run(lambda x, w, b: F.leaky_relu(F.conv2d(x, w, b, 2, 1), 0.2), x, w, b)
     out = run(lambda x, w, b: ops.conv2d(x, w, b, 2, 1, act_kind=ops.ACT_LRELU, slope=0.2), x.to(dev), w.to(dev), b.to(dev),
               ops.input_grads_only)
+    for o, r in zip(out, ref):
+        assert rel_err(o, r) < 5e-5
+    ref = run(lambda x, w, b: F.avg_pool2d(F.leaky_relu(F.conv2d(x, w, b, 2, 1), 0.2), 2), x, w, b)
+    out = run(lambda x, w, b: ops.conv2d(x, w, b, 2, 1, act_kind=ops.ACT_LRELU, slope=0.2, pool=True),
+              x.to(dev), w.to(dev), b.to(dev), ops.input_grads_only)
     for o, r in zip(out, ref):
         assert rel_err(o, r) < 5e-5
 
@@ -201,6 +210,28 @@ def test_norm_fwd_bwd_bwdbwd(dev, kind, shape, act):
     names = ['y', 'gx', 'ggamma', 'gbeta', 'dd_gy', 'dd_x', 'dd_gamma']
     for n, o, r in zip(names, out, ref):
         assert rel_err(o, r) < 2e-4, n     # fp32 statistics vs an fp64 reference
+
+
+@pytest.mark.parametrize("kind", NORM_KINDS)
+def test_norm_add_norm_act(dev, kind):
+    """relu(norm(a) + norm(b)): the fused residual-block tail against the composed torch ops, first-order gradients."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    shape = (3, 8, 12, 12)
+    a = torch.randn(shape, generator=g) * 2 + 0.5; b = torch.randn(shape, generator=g) - 1.0
+    par = [torch.randn(8, generator=g) * 0.5 + 1 for _ in range(2)] + [torch.randn(8, generator=g) * 0.3 for _ in range(2)]
+    gy = torch.randn(shape, generator=g)
+
+    def run(fn, dev_):
+        t = [v.clone().to(dev_).requires_grad_(True) for v in (a, b, *par)]
+        y = fn(*t)
+        y.backward(gy.to(dev_))
+        return [y] + [v.grad for v in t]
+    ref = run(lambda a, b, ga, gb, ba, bb: F.relu(_torch_norm(kind, a, ga, ba) + _torch_norm(kind, b, gb, bb)), 'cpu')
+    code = {'batch': ops.NORM_BATCH, 'instance': ops.NORM_INSTANCE, 'layer': ops.NORM_LAYER}[kind]
+    out = run(lambda a, b, ga, gb, ba, bb: ops.norm_add_norm_act(a, ga, ba, b, gb, bb, code, ops.ACT_RELU), dev)
+    for o, r in zip(out, ref):
+        assert rel_err(o, r) < 5e-5
 
 
 def test_batchnorm_running_stats(dev):
