@@ -31,6 +31,9 @@ __device__ __forceinline__ int2 ctab_get(ctab_ptr t, int k) { return make_int2(t
 
 namespace {
 
+#ifndef IGEMM_OCC
+#define IGEMM_OCC 3
+#endif
 constexpr int BK = 16;
 constexpr int MODE_GATHER = 0;   // FWD and DGRAD: A = packed weights, B = gathered activations
 constexpr int MODE_WGRAD = 1;    // A = gy, B = gathered activations, reduction over pixels
@@ -75,6 +78,7 @@ struct IgemmParams {
     struct Phase { long long a_off; int tab_off, N, nchunks, QW, QHW, OPY, OPX; } ph[4];
     long long slab_stride; // elements between split slabs
     int C;                 // channel count of the gathered tensor
+    int x_bytes, a_bytes;  // sizes of the X and A operands (buffer-load bounds)
     int act; float slope;  // GATHER epilogue activation (applied with the bias, only when splits == 1)
 };
 
@@ -83,7 +87,7 @@ struct IgemmParams {
 // and the spatial offset are computed once per chunk and every load is base + per-channel constant. Without it
 // (RGB stems, Cin = 3) each element is decoded separately.
 template <int BM, int BN, int WM, int WN, int MODE, bool UT>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
+__global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams p)
 {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int PAD = (MODE == MODE_WGRAD) ? (UT ? 1 : 2) : 0;
@@ -154,11 +158,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     constexpr int RA = (MODE == MODE_GATHER) ? A_PER * 4 : WA_PER;
     constexpr int RB = (MODE == MODE_GATHER) ? B_PER : WB_PER;
     float ra[RA], rb[RB];
-    unsigned ok_a = 0u, ok_b = 0u;     // validity bits of the staged elements; applied when they are written to LDS,
-                                       // so nothing consumes a load result before the MFMAs of the current chunk
+
+    // Every global read of the loop is a buffer load: a 128-bit resource (base, size) in SGPRs + a per-lane unsigned byte
+    // offset + a wave-uniform byte offset.  Per load that is one instruction and no address arithmetic (a flat load needs
+    // a 64-bit VALU add), and an offset at or beyond the buffer size returns 0 in hardware: padding taps, ragged tile
+    // edges and k-tails are expressed as the out-of-range offset OOB instead of selects on the loaded values.
+    // (Host side checks that both operands are smaller than 2 GiB.)
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pA), 0, p.a_bytes - (int)((pA - p.A) * 4), 0x00020000);
+    auto ld1 = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, soff, 0));
+    };
 
     // GATHER-mode column decode (fixed for the whole K loop)
     int g_ybase = 0, g_xbase = 0, g_off = 0, g_krow0 = 0;
+    // weight tile: one float4 per thread and chunk through a flat pointer advanced by BK rows per chunk (this hipcc
+    // lowers the 64/128-bit buffer-load builtins to a single dword, so only the dword gathers are buffer loads)
+    const float* a_ptr[(MODE == MODE_GATHER) ? A_PER : 1];
     if constexpr (MODE == MODE_GATHER) {
         const int n_local = tid % BN;
         g_krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
@@ -172,16 +190,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         g_ybase = valid ? qy * p.SY : -(1 << 20);               // invalid column never passes the bound test
         g_xbase = qx * p.SX;
         g_off = b * p.XCHW;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+            a_ptr[i] = pA + (size_t)(c_begin * BK + row) * p.Mpad + m0 + c4 * 4;      // Mpad % BM == 0 in GATHER mode
+        }
     }
     // WGRAD-mode column decode: the gather-table entries of this thread's columns are loop-invariant -> registers
     constexpr int NTAB = (MODE == MODE_WGRAD) ? (UT ? 1 : WB_PER) : 1;
     int2 w_tab[NTAB];
+    unsigned w_rowoob[(MODE == MODE_WGRAD) ? WA_PER : 1];       // OOB for gy rows beyond M, else 0
     const int w_c0 = tid >> 4;
     if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
         for (int i = 0; i < NTAB; ++i) {
             const int n = UT ? (n0 + w_c0 * WB_PER) : (n0 + w_c0 + 16 * i);
             w_tab[i] = (n < pN) ? pktab[n] : make_int2(0, (int)0x80008000);  // dy=dx=-32768: always out of range
+        }
+#pragma unroll
+        for (int i = 0; i < WA_PER; ++i) {
+            const int m = UT ? (m0 + w_c0 * WA_PER + i) : (m0 + w_c0 + 16 * i);
+            w_rowoob[i] = m < p.M ? 0u : OOB;
         }
     }
 
@@ -193,15 +223,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         if constexpr (MODE == MODE_GATHER) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
-                const int idx = tid + i * 256;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < A_V4) {
-                    const int row = idx / (BM / 4);
-                    const int c4 = idx % (BM / 4);
-                    const int m = m0 + c4 * 4;
-                    if (m < p.Mpad) v = *reinterpret_cast<const float4*>(pA + (size_t)(k0 + row) * p.Mpad + m);
+                if (tid + i * 256 < A_V4) {                     // compile-time true except BM = 32 (uniform per wave)
+                    const float4 v = *reinterpret_cast<const float4*>(a_ptr[i]);
+                    ra[i * 4 + 0] = v.x; ra[i * 4 + 1] = v.y; ra[i * 4 + 2] = v.z; ra[i * 4 + 3] = v.w;
+                    a_ptr[i] += BK * p.Mpad;
                 }
-                ra[i * 4 + 0] = v.x; ra[i * 4 + 1] = v.y; ra[i * 4 + 2] = v.z; ra[i * 4 + 3] = v.w;
             }
             if constexpr (UT) {
                 // uniform: the whole chunk is one tap (e0.y) and its channels are consecutive planes from e0.x
@@ -210,25 +236,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 const int iy = g_ybase + (e0.y >> 16);
                 const int ix = g_xbase + (int)(short)(e0.y & 0xffff);
                 const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
-                // out-of-range pixels read offset 0 of the channel plane (always mapped) and are zeroed when staged
-                const int sp = ok ? g_off + (iy >> p.ups) * p.XW + (ix >> p.ups) : 0;
-                const float* xb = p.X + e0.x + g_krow0 * p.XHW;         // wave-uniform base
+                const unsigned voff = ok ? 4u * (unsigned)(g_off + (iy >> p.ups) * p.XW + (ix >> p.ups)) : OOB;
+                const int soff = (e0.x + g_krow0 * p.XHW) * 4;
 #pragma unroll
-                for (int i = 0; i < B_PER; ++i) rb[i] = (xb + (size_t)(i * KSTEP) * p.XHW)[sp];
-                ok_b = ok ? 0xffffffffu : 0u;
+                for (int i = 0; i < B_PER; ++i) rb[i] = ld1(x_rs, voff, soff + i * KSTEP * p.XHW * 4);
             } else {
-                unsigned okb = 0u;
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
                     const int2 e = ctab_get(ctab, k0 + g_krow0 + i * KSTEP);
                     const int iy = g_ybase + (e.y >> 16);
                     const int ix = g_xbase + (int)(short)(e.y & 0xffff);
                     const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
-                    const int off = g_off + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
-                    rb[i] = p.X[ok ? off : 0];                     // branch-free: element 0 is always mapped
-                    okb |= (ok ? 1u : 0u) << i;
+                    rb[i] = ld1(x_rs, ok ? 4u * (unsigned)(g_off + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups)) : OOB, 0);
                 }
-                ok_b = okb;
             }
         } else {
             const int k_local = tid & 15;
@@ -242,49 +262,29 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             const int ybase = kv ? (int)qy * p.SY : -(1 << 20);
             const int xbase = (int)qx * p.SX;
             const int xoff = (int)b * p.XCHW;
-            unsigned oka = 0u;
-            if constexpr (UT) {
-                // A: gy[b][m][r], rows m = mrow0 + i
-                const int mrow0 = m0 + w_c0 * WA_PER;
-                const int a_off = ((int)b * p.M + mrow0) * pQHW + (int)r;
+            // A: gy[b][m][r]
+            const unsigned a_base = kv ? 4u * (unsigned)(((int)b * p.M + m0 + (UT ? w_c0 * WA_PER : w_c0)) * pQHW + (int)r) : OOB;
 #pragma unroll
-                for (int i = 0; i < WA_PER; ++i) {
-                    const bool ok = kv && (mrow0 + i) < p.M;
-                    ra[i] = pA[ok ? a_off + i * pQHW : 0];
-                    oka |= (ok ? 1u : 0u) << i;
-                }
+            for (int i = 0; i < WA_PER; ++i) ra[i] = ld1(a_rs, a_base | w_rowoob[i], (UT ? i : 16 * i) * pQHW * 4);
+            if constexpr (UT) {
                 // B: x[b][ci0 + i][pixel shifted by this thread's tap]
                 const int2 e = w_tab[0];
                 const int iy = ybase + (e.y >> 16);
                 const int ix = xbase + (int)(short)(e.y & 0xffff);
                 const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
-                const int sp = ok ? xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups) : 0;
+                const unsigned voff = ok ? 4u * (unsigned)(xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups)) : OOB;
 #pragma unroll
-                for (int i = 0; i < WB_PER; ++i) rb[i] = (p.X + i * p.XHW)[sp];   // uniform base + one vgpr offset
-                ok_b = ok ? 0xffffffffu : 0u;
+                for (int i = 0; i < WB_PER; ++i) rb[i] = ld1(x_rs, voff, i * p.XHW * 4);
             } else {
-                const float* ap = pA + (size_t)b * p.M * pQHW + r;
-#pragma unroll
-                for (int i = 0; i < WA_PER; ++i) {
-                    const int m = m0 + w_c0 + 16 * i;
-                    const bool ok = kv && m < p.M;
-                    ra[i] = ap[ok ? (size_t)m * pQHW : 0];
-                    oka |= (ok ? 1u : 0u) << i;
-                }
-                unsigned okb = 0u;
 #pragma unroll
                 for (int i = 0; i < WB_PER; ++i) {
                     const int2 e = w_tab[i];
                     const int iy = ybase + (e.y >> 16);
                     const int ix = xbase + (int)(short)(e.y & 0xffff);
                     const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
-                    const int off = xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups);
-                    rb[i] = p.X[ok ? off : 0];
-                    okb |= (ok ? 1u : 0u) << i;
+                    rb[i] = ld1(x_rs, ok ? 4u * (unsigned)(xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups)) : OOB, 0);
                 }
-                ok_b = okb;
             }
-            ok_a = oka;
         }
     };
 
@@ -303,23 +303,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 }
             }
             const int n_local = tid % BN;
-            if constexpr (UT) {
-                const bool okb = ok_b != 0u;
 #pragma unroll
-                for (int i = 0; i < B_PER; ++i) bs[(g_krow0 + i * KSTEP) * LDB + n_local] = okb ? rb[i] : 0.f;
-            } else {
-#pragma unroll
-                for (int i = 0; i < B_PER; ++i)
-                    bs[(g_krow0 + i * KSTEP) * LDB + n_local] = ((ok_b >> i) & 1u) ? rb[i] : 0.f;
-            }
+            for (int i = 0; i < B_PER; ++i) bs[(g_krow0 + i * KSTEP) * LDB + n_local] = rb[i];
         } else {
             const int k_local = tid & 15;
 #pragma unroll
-            for (int i = 0; i < WA_PER; ++i)
-                as[k_local * LDA + (UT ? w_c0 * WA_PER + i : w_c0 + 16 * i)] = ((ok_a >> i) & 1u) ? ra[i] : 0.f;
+            for (int i = 0; i < WA_PER; ++i) as[k_local * LDA + (UT ? w_c0 * WA_PER + i : w_c0 + 16 * i)] = ra[i];
 #pragma unroll
-            for (int i = 0; i < WB_PER; ++i)
-                bs[k_local * LDB + (UT ? w_c0 * WB_PER + i : w_c0 + 16 * i)] = ((ok_b >> i) & 1u) ? rb[i] : 0.f;
+            for (int i = 0; i < WB_PER; ++i) bs[k_local * LDB + (UT ? w_c0 * WB_PER + i : w_c0 + 16 * i)] = rb[i];
         }
     };
 
@@ -340,18 +331,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             __builtin_amdgcn_sched_barrier(0);
             const float* as = As + buf * A_ELEMS + kh * LDA + wm * (TM * 32) + l31;
             const float* bs = Bs + buf * B_ELEMS + kh * LDB + wn * (TN * 32) + l31;
+            // operands of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued (two register sets), so
+            // the LDS latency sits under 4 MFMAs instead of between them
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
-                float a[TM], b[TN];
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < BK / 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = as[ks * 2 * LDA + i * 32];
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = as[(ks + 1) * 2 * LDA + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = bs[ks * 2 * LDB + j * 32];
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = bs[(ks + 1) * 2 * LDB + j * 32];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                if (ks + 1 < BK / 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);     // DS reads of the next k-step first ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);     // ... then this k-step's MFMAs
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) store_tiles(buf ^ 1);
@@ -739,10 +743,10 @@ inline int check_desc(const sempyr_conv_desc* d, Geometry& g) {
     g.Ho = (g.GHin + 2 * d->pad - d->kh) / d->stride + 1;
     g.Wo = (g.GWin + 2 * d->pad - d->kw) / d->stride + 1;
     g.T = d->kh * d->kw;
-    const long long lim = (1ll << 31) - 1;
+    const long long lim = (1ll << 29) - 1;                       // 2 GiB of fp32: the buffer-load offset range
     if ((long long)d->B * d->Cin * g.GHin * g.GWin > lim || (long long)d->B * d->Cout * g.Ho * g.Wo > lim ||
         (long long)d->Cout * d->Cin * g.T > lim)
-        SEMPYR_FAIL("conv: tensor larger than 2^31 elements");
+        SEMPYR_FAIL("conv: tensor larger than 2^29 elements");
     return 0;
 }
 
@@ -1047,6 +1051,7 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     const int splits = pl.splits[0];
     p.chunks_per_split = ceil_div(p.nchunks, splits);
     p.C = d->Cin;
+    p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = (int)(pl.wpack_floats * 4);
     if (splits == 1) { p.Out = y; p.bias = bias; p.slab_stride = 0; p.act = act; p.slope = slope; }
     else { p.Out = (float*)ws; p.bias = nullptr; p.slab_stride = out_numel; }
     if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) return launch_rgb3x3(p, st);
@@ -1113,6 +1118,7 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
             p.chunks_per_split = ceil_div(p.nchunks, splits);
         }
         p.C = d->Cout;
+        p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = (int)(pl.wpack_floats * 4);
         if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_DGRAD)) return launch_rgb3x3(p, st);
         if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cout % BK == 0, st)) return rc;
     }
@@ -1144,6 +1150,7 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     const int splits = pl.splits[0];
     p.chunks_per_split = ceil_div(p.nchunks, splits);
     p.Out = (float*)ws; p.slab_stride = (long long)d->Cout * Nn;
+    p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = d->B * d->Cout * pl.Ho * pl.Wo * 4;
     if (int rc = launch_cfg<MODE_WGRAD>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
     const int total = d->Cout * d->Cin * T;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st,
