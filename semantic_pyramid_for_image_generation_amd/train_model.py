@@ -182,6 +182,11 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
     return loses_dictionary
 
 
+def _samplewise(module):
+    """True when no submodule computes statistics across the batch (BatchNorm), i.e. f(cat(a, b)) == cat(f(a), f(b))."""
+    return not any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in module.modules())
+
+
 def train_discriminator(generator, discriminator, discriminator_loss_fn, discriminator_optimizer, real_images, features, masks,
                         z=None, alpha=None):
     """One critic step (reference :122-145): real/fake logits + 10 * gradient penalty (double backward)."""
@@ -193,8 +198,15 @@ def train_discriminator(generator, discriminator, discriminator_loss_fn, discrim
     with torch.no_grad():                                                 # reference: forward with graph, then .detach()
         fake_images = generator(z, features, masks)
 
-    real_images_d_logit = discriminator(real_images)
-    fake_images_d_logit = discriminator(fake_images)
+    if _samplewise(discriminator):
+        # no layer mixes samples (instance / layer norm or none): one pass over both batches gives the same logits as the
+        # reference's two passes and fills the small late layers twice as well
+        n = real_images.shape[0]
+        logits = discriminator(torch.cat([real_images, fake_images]))
+        real_images_d_logit, fake_images_d_logit = logits[:n], logits[n:]
+    else:
+        real_images_d_logit = discriminator(real_images)
+        fake_images_d_logit = discriminator(fake_images)
     real_images_d_loss, fake_images_d_loss = discriminator_loss_fn(real_images_d_logit, fake_images_d_logit)
     gp = gradient_penalty(discriminator, real_images, fake_images, alpha)
 

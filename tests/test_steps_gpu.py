@@ -9,7 +9,12 @@ Two kinds of check:
     CPU path is 1.3e-3..1.9e-3 off with 8 threads; torch's OWN GPU kernels (every sempyr op swapped for
     torch.nn.functional on the same GPU, tools/diag_bisect.py) are 1.6e-3 .. 1.9e-2 off — 1.9e-2 on
     conv_block2's weight — and the HIP path measures the same 1.2e-3 .. 1.9e-2 on the same tensors, bit-identical
-    from run to run.  A formula error shows up as O(1), far outside that band;
+    from run to run.  A formula error shows up as O(1), far outside that band.  On top of that, at most 0.5 % of a
+    tensor's elements (at least one) may be off by up to 0.2 of its max-abs: one LeakyReLU pre-activation at round-off
+    distance from 0 that lands on the other side flips act' between 1 and 0.2 for that element and moves exactly the
+    gradient entries it feeds (measured with the real+fake critic passes batched, which changes the split-K summation
+    order of conv_block5: 1 of 512 channels of its norm bias gradient moved by 7.1e-2 of scale, the other 511 agree to
+    1e-6; tools/diag_grads.py);
   * the reference-generated 3-step trajectory (D, G, D with the reference's own z / alpha draws): losses before
     the first update to 1e-3; later ones looser, because Adam's first update is lr*g/(|g|+eps) ~ lr*sign(g), which
     turns round-off in structurally-zero gradients (conv biases in front of a norm layer) into +-lr steps: the
@@ -32,8 +37,10 @@ pytestmark = pytest.mark.gpu
 def _grad_close(name, got, want, global_max):
     got = got.detach().cpu().double(); want = want.detach().cpu().double()
     scale = max(float(want.abs().max()), 1e-3 * global_max)
-    err = float((got - want).abs().max())
-    assert err <= 3e-2 * scale, (name, err, scale)
+    err = (got - want).abs()
+    outliers = int((err > 3e-2 * scale).sum())
+    assert outliers <= max(1, err.numel() // 200), (name, outliers, err.numel(), float(err.max()), scale)
+    assert float(err.max()) <= 0.2 * scale, (name, float(err.max()), scale)
 
 
 def _setup(dev, gen_type, norm, div, seed, B=2):
