@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
     constexpr int B_PER = BK / KSTEP;
     // WGRAD: thread owns pixel (reduction row) k_local = tid % 16 and WA_PER rows of gy / WB_PER columns of x.
     constexpr int WA_PER = BM / 16, WB_PER = BN / 16;
+    // UT WGRAD: a thread's WB_PER columns are NG groups of CPG consecutive columns (one filter tap per group). One group
+    // of 16 needs channels % 16 == 0 only; the 192-wide tile (3 x 64 columns: no padding for Cin*9 = 576, 1152) uses 3
+    // groups of 4 so that no group straddles a tap boundary.
+    constexpr int CPG = (BN == 192) ? 4 : WB_PER, NG = WB_PER / CPG;
     constexpr int RA = (MODE == MODE_GATHER) ? A_PER * 4 : WA_PER;
     constexpr int RB = (MODE == MODE_GATHER) ? B_PER : WB_PER;
     float ra[RA], rb[RB];
@@ -198,14 +202,14 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
         }
     }
     // WGRAD-mode column decode: the gather-table entries of this thread's columns are loop-invariant -> registers
-    constexpr int NTAB = (MODE == MODE_WGRAD) ? (UT ? 1 : WB_PER) : 1;
+    constexpr int NTAB = (MODE == MODE_WGRAD) ? (UT ? NG : WB_PER) : 1;
     int2 w_tab[NTAB];
     unsigned w_rowoob[(MODE == MODE_WGRAD) ? WA_PER : 1];       // OOB for gy rows beyond M, else 0
     const int w_c0 = tid >> 4;
     if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
         for (int i = 0; i < NTAB; ++i) {
-            const int n = UT ? (n0 + w_c0 * WB_PER) : (n0 + w_c0 + 16 * i);
+            const int n = UT ? (n0 + i * 16 * CPG + w_c0 * CPG) : (n0 + w_c0 + 16 * i);
             w_tab[i] = (n < pN) ? pktab[n] : make_int2(0, (int)0x80008000);  // dy=dx=-32768: always out of range
         }
 #pragma unroll
@@ -268,13 +272,16 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
             for (int i = 0; i < WA_PER; ++i) ra[i] = ld1(a_rs, a_base | w_rowoob[i], (UT ? i : 16 * i) * pQHW * 4);
             if constexpr (UT) {
                 // B: x[b][ci0 + i][pixel shifted by this thread's tap]
-                const int2 e = w_tab[0];
-                const int iy = ybase + (e.y >> 16);
-                const int ix = xbase + (int)(short)(e.y & 0xffff);
-                const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
-                const unsigned voff = ok ? 4u * (unsigned)(xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups)) : OOB;
 #pragma unroll
-                for (int i = 0; i < WB_PER; ++i) rb[i] = ld1(x_rs, voff, i * p.XHW * 4);
+                for (int g = 0; g < NG; ++g) {
+                    const int2 e = w_tab[g];
+                    const int iy = ybase + (e.y >> 16);
+                    const int ix = xbase + (int)(short)(e.y & 0xffff);
+                    const bool ok = ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+                    const unsigned voff = ok ? 4u * (unsigned)(xoff + e.x + (iy >> p.ups) * p.XW + (ix >> p.ups)) : OOB;
+#pragma unroll
+                    for (int i = 0; i < CPG; ++i) rb[g * CPG + i] = ld1(x_rs, voff, i * p.XHW * 4);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < WB_PER; ++i) {
@@ -310,7 +317,8 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
 #pragma unroll
             for (int i = 0; i < WA_PER; ++i) as[k_local * LDA + (UT ? w_c0 * WA_PER + i : w_c0 + 16 * i)] = ra[i];
 #pragma unroll
-            for (int i = 0; i < WB_PER; ++i) bs[k_local * LDB + (UT ? w_c0 * WB_PER + i : w_c0 + 16 * i)] = rb[i];
+            for (int i = 0; i < WB_PER; ++i)
+                bs[k_local * LDB + (UT ? (i / CPG) * 16 * CPG + w_c0 * CPG + (i % CPG) : w_c0 + 16 * i)] = rb[i];
         }
     };
 
@@ -689,22 +697,33 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3 };
+enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3, CFG_64x192 = 4, CFG_64x128 = 5 };
 
-inline int pick_cfg(int Mpad) {
+inline int pick_cfg(int Mpad, long long N = 1ll << 40) {
     if (Mpad % 128 == 0) return CFG_128x128;
-    if (Mpad % 64 == 0) return CFG_64x256;
+    if (Mpad % 64 == 0) {
+        // mid-size pixel counts (64 channels at 64x64 x batch 16): 64x64 tiles fill the chip without split-K slabs and
+        // their combine pass (measured 0.121 -> 0.103 ms on the critic's 64->64 4x4 s2 block)
+        const long long t256 = (Mpad / 64) * ((N + 255) / 256), t64 = (Mpad / 64) * ((N + 63) / 64);
+        if (t256 < 512 && t64 >= 512) return CFG_64x64;
+        return CFG_64x256;
+    }
     return CFG_32x256;
 }
 inline void cfg_dims(int cfg, int& bm, int& bn) {
     if (cfg == CFG_128x128) { bm = 128; bn = 128; }
     else if (cfg == CFG_64x256) { bm = 64; bn = 256; }
     else if (cfg == CFG_64x64) { bm = 64; bn = 64; }
+    else if (cfg == CFG_64x192) { bm = 64; bn = 192; }
+    else if (cfg == CFG_64x128) { bm = 64; bn = 128; }
     else { bm = 32; bn = 256; }
 }
 // WGRAD: the N dimension (Cin*taps) can be tiny (27 for an RGB stem, 64 for a 1x1 skip): use a narrow tile there
-inline int pick_cfg_wgrad(int Mpad, int Nn) {
+inline int pick_cfg_wgrad(int Mpad, int Nn, bool uniform_tap) {
     if (Nn <= 64 && Mpad % 64 == 0) return CFG_64x64;
+    // 64-row problems whose column count is a multiple of 192 but pads by > 10 % in 256-wide tiles (576 -> 768)
+    if (uniform_tap && Mpad % 128 != 0 && Mpad % 64 == 0 && Nn % 192 == 0 && (Nn + 255) / 256 * 256 * 10 > Nn * 11)
+        return CFG_64x192;
     return pick_cfg(Mpad);
 }
 
@@ -808,6 +827,10 @@ int launch_cfg_ut(int cfg, const IgemmParams& p, int splits, hipStream_t st) {
         case CFG_128x128: return launch_igemm<128, 128, 2, 2, MODE, UT>(p, splits, st);
         case CFG_64x256:  return launch_igemm<64, 256, 1, 4, MODE, UT>(p, splits, st);
         case CFG_64x64:   return launch_igemm<64, 64, 2, 2, MODE, UT>(p, splits, st);
+        case CFG_64x128:  return launch_igemm<64, 128, 2, 2, MODE, UT>(p, splits, st);
+        case CFG_64x192:
+            if constexpr (MODE == MODE_WGRAD && UT) return launch_igemm<64, 192, 2, 2, MODE, UT>(p, splits, st);
+            else { sempyr_set_error("conv: the 64x192 tile is a uniform-tap WGRAD configuration"); return SEMPYR_ERR_INVALID; }
         default:          return launch_igemm<32, 256, 1, 4, MODE, UT>(p, splits, st);
     }
 }
@@ -897,7 +920,9 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         plan->K[0] = d->Cin * g.T; plan->Kpad[0] = (plan->K[0] + BK - 1) / BK * BK;
         plan->tab_off[0] = 0; plan->tab_entries = plan->Kpad[0];
         plan->Mpad = (d->Cout + 31) / 32 * 32;
-        plan->cfg = pick_cfg(plan->Mpad); cfg_dims(plan->cfg, bm, bn);
+        plan->cfg = pick_cfg(plan->Mpad, (long long)d->B * g.Ho * g.Wo);
+        { static const int f = env_int("SEMPYR_FORCE_CFG", -1); if (f >= 0 && plan->Mpad % (f == CFG_128x128 ? 128 : f == CFG_32x256 ? 32 : 64) == 0) plan->cfg = f; }
+        cfg_dims(plan->cfg, bm, bn);
         plan->wpack_floats = (long long)plan->Kpad[0] * plan->Mpad;
         const long long N = (long long)d->B * g.Ho * g.Wo;
         int cps;
@@ -937,7 +962,7 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         const int Nn = (d->Cin * g.T + BK - 1) / BK * BK;       // = FWD Kpad: columns incl. padding
         plan->tab_off[0] = 0; plan->tab_entries = Nn;
         plan->Mpad = (d->Cout + 31) / 32 * 32;
-        plan->cfg = pick_cfg_wgrad(plan->Mpad, Nn); cfg_dims(plan->cfg, bm, bn);
+        plan->cfg = pick_cfg_wgrad(plan->Mpad, Nn, d->Cin % BK == 0); cfg_dims(plan->cfg, bm, bn);
         plan->wpack_floats = 0;
         int cps;
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(Nn, bn), plan->Kpad[0] / BK, plan->splits[0], cps);

@@ -7,6 +7,15 @@ from semantic_pyramid_for_image_generation_amd._lib import CONV_FWD, CONV_DGRAD,
 
 dev = torch.device('cuda:0')
 # (name, B, Cin, H, W, Cout, k, s, p, ups)
+MID = [
+    ('D.b1 64->64 4x4s2 @128', 16, 64, 128, 128, 64, 4, 2, 1, 0),
+    ('C.l1 64->64 3x3 @64', 16, 64, 64, 64, 64, 3, 1, 1, 0),
+    ('G.b6 128->64 3x3 ups @32', 16, 128, 32, 32, 64, 3, 1, 1, 1),
+    ('D.b2 64->128 4x4s2 @64', 16, 64, 64, 64, 128, 4, 2, 1, 0),
+    ('C.l2 128->128 3x3 @32', 16, 128, 32, 32, 128, 3, 1, 1, 0),
+    ('G.b5 256->128 3x3 ups @16', 16, 256, 16, 16, 128, 3, 1, 1, 1),
+    ('C.l3 256->256 3x3 @16', 16, 256, 16, 16, 256, 3, 1, 1, 0),
+]
 SMALL = [
     ('D.b3 128->256 4x4s2 @32', 16, 128, 32, 32, 256, 4, 2, 1, 0),
     ('D.b4 256->512 4x4s2 @16', 16, 256, 16, 16, 512, 4, 2, 1, 0),
@@ -49,7 +58,7 @@ def timeit(fn, reps=5):
 
 print('%-34s %8s %8s %8s   (ms / TFLOP/s)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
 import sys
-for name, B, Cin, H, W, Cout, k, s, p, ups in (SMALL if 'small' in sys.argv else SHAPES):
+for name, B, Cin, H, W, Cout, k, s, p, ups in (SMALL if 'small' in sys.argv else MID if 'mid' in sys.argv else SHAPES):
     plan = ops.get_plan((B, Cin, H, W, Cout, k, k, s, p, ups), dev)
     x = torch.randn(B, Cin, H, W, device=dev)
     w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
