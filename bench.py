@@ -206,8 +206,15 @@ def main():
             out["eval_config"] = "eval_model.py loop, gen-type res, batch 8, 4 levels x 4 noises, classifier pass included"
         if timing and kl.value > 0:
             achieved = cycle_flops * a.steps / (kms.value * 1e-3) / 1e12
+            # HBM-side bytes per launch of the same kernel: PMC passes cannot run inside this process, so the committed
+            # summary of tools/pmc_traffic.sh (same command line, see its "method" field) is quoted; None if absent.
+            traffic = None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                               "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                                "kernel": "igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv fwd/dgrad/wgrad)",
                                "launches": int(kl.value), "avg_launch_us": 1000.0 * kms.value / kl.value,
                                "kernel_ms_total": kms.value, "kernel_time_share": kms.value * 1e-3 / elapsed,
