@@ -1,1 +1,2 @@
-for tb in 512 256; do for mc in 4 8 16; do echo "TARGET_BLOCKS=$tb MIN_CHUNKS=$mc"; SEMPYR_TARGET_BLOCKS=$tb SEMPYR_MIN_CHUNKS=$mc timeout -k 10 120 python tools/bench_conv.py small 2>&1 | grep -v "^shape"; done; done
+for tb in 768 1536; do echo "TARGET_BLOCKS=$tb"; SEMPYR_TARGET_BLOCKS=$tb timeout -k 10 120 python tools/bench_conv.py 2>&1 | grep -v amdgpu.ids;  SEMPYR_TARGET_BLOCKS=$tb timeout -k 10 120 python tools/bench_conv.py mid 2>&1 | grep -v "amdgpu.ids\|shape"; done
+echo "TARGET_BLOCKS=512 mid";  timeout -k 10 120 python tools/bench_conv.py mid 2>&1 | grep -v "amdgpu.ids\|shape"
