@@ -39,17 +39,45 @@ __device__ __forceinline__ void row_reduce(float (&v)[NS], float* sh) {
     }
 }
 
-// per-row mean and M2 = sum (x - mean)^2 (two passes over the row; the second hits L2)
+// per-row mean and M2 = sum (x - mean)^2.
+// Rows served by one wave (TPR = 64, < 2048 elements) are read twice (the second pass hits L1/L2).  Long rows
+// (TPR = 256: up to 256 KB per row, 268 MB per tensor -- beyond L2 and the Infinity Cache) are read ONCE, accumulating
+// sum(x - p) and sum (x - p)^2 around a pivot p = mean of the row's first four elements; with p inside the data's range
+// M2 = S2 - S1^2/n loses about one bit, not the catastrophic cancellation of raw sum / sum-of-squares.
 template <int TPR>
 __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ x, int rows, int len, int vec,
                                                           float* __restrict__ mean_out, float* __restrict__ m2_out)
 {
-    __shared__ float sh[4];
+    __shared__ float sh[8];
     constexpr int RPB = 256 / TPR;
     const int row = blockIdx.x * RPB + threadIdx.x / TPR;
     const int t = threadIdx.x % TPR;
     const bool live = row < rows;
     const float* xr = x + (size_t)(live ? row : 0) * len;
+    if constexpr (TPR == 256) {
+        const float p = len >= 4 ? 0.25f * ((xr[0] + xr[1]) + (xr[2] + xr[3])) : xr[0];
+        float s[2] = {0.f, 0.f};
+        if (live) {
+            if (vec) {
+                const float4* x4 = reinterpret_cast<const float4*>(xr);
+                for (int i = t; i < len / 4; i += TPR) {
+                    const float4 v = x4[i];
+                    const float a = v.x - p, b = v.y - p, c = v.z - p, d = v.w - p;
+                    s[0] += (a + b) + (c + d);
+                    s[1] += (a * a + b * b) + (c * c + d * d);
+                }
+            } else {
+                for (int i = t; i < len; i += TPR) { const float a = xr[i] - p; s[0] += a; s[1] += a * a; }
+            }
+        }
+        row_reduce<TPR, 2>(s, sh);
+        if (live && t == 0) {
+            const float dm = s[0] / (float)len;
+            mean_out[row] = p + dm;
+            m2_out[row] = fmaxf(s[1] - s[0] * dm, 0.f);
+        }
+        return;
+    }
     float s[1] = {0.f};
     if (live) {
         if (vec) {
