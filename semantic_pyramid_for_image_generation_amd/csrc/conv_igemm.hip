@@ -531,7 +531,10 @@ __global__ __launch_bounds__(256) void gather_small_m_kernel(const IgemmParams p
 // re-read the same three image rows back to back (L1 hits).  Weights sit in LDS as [channel][tap slot] float4 (uniform
 // address -> broadcast reads); the slot of a reduction index comes from the gather table, so FWD and DGRAD (flipped
 // taps) share the kernel.  The next channel's pixels are in flight while the current one is accumulated.
-template <int NM>
+// WAVE_ROW (image width == 256 = 64 lanes x 4 pixels): a wave is exactly one image row, so the pixel left / right of a
+// lane's quad is the neighbouring lane's (one DPP wave shift each, zero at the ends = the padding) and only the three
+// aligned float4 loads per channel remain.
+template <int NM, bool WAVE_ROW>
 __global__ __launch_bounds__(256) void rgb3x3_kernel(const IgemmParams p)
 {
     extern __shared__ float4 wl[];
@@ -574,18 +577,23 @@ __global__ __launch_bounds__(256) void rgb3x3_kernel(const IgemmParams p)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             s.c[d] = *reinterpret_cast<const float4*>(pl + ro[d]);
-            s.l[d] = pl[ro[d] + xl];
-            s.r[d] = pl[ro[d] + xr];
+            if constexpr (!WAVE_ROW) { s.l[d] = pl[ro[d] + xl]; s.r[d] = pl[ro[d] + xr]; }
         }
     };
     auto compute = [&](const Stage& s, int ci) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float v[6];
-            v[0] = (rok[d] && lok) ? s.l[d] : 0.f;
             v[1] = rok[d] ? s.c[d].x : 0.f; v[2] = rok[d] ? s.c[d].y : 0.f;
             v[3] = rok[d] ? s.c[d].z : 0.f; v[4] = rok[d] ? s.c[d].w : 0.f;
-            v[5] = (rok[d] && rrok) ? s.r[d] : 0.f;
+            if constexpr (WAVE_ROW) {
+                // wave_shr:1 / wave_shl:1 with bound_ctrl off and old = 0: lane 0 / lane 63 receive the zero padding
+                v[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[4]), 0x138, 0xf, 0xf, false));
+                v[5] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[1]), 0x130, 0xf, 0xf, false));
+            } else {
+                v[0] = (rok[d] && lok) ? s.l[d] : 0.f;
+                v[5] = (rok[d] && rrok) ? s.r[d] : 0.f;
+            }
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const float4 w4 = wl[ci * 9 + d * 3 + t];
@@ -930,8 +938,13 @@ int launch_rgb3x3(const IgemmParams& p, hipStream_t st) {
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
-    if (p.M <= 3) hipLaunchKernelGGL(rgb3x3_kernel<3>, grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(rgb3x3_kernel<4>, grid, dim3(256), lds, st, p);
+    if (p.GW == 256) {
+        if (p.M <= 3) hipLaunchKernelGGL((rgb3x3_kernel<3, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((rgb3x3_kernel<4, true>), grid, dim3(256), lds, st, p);
+    } else {
+        if (p.M <= 3) hipLaunchKernelGGL((rgb3x3_kernel<3, false>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((rgb3x3_kernel<4, false>), grid, dim3(256), lds, st, p);
+    }
     if (e1) (void)hipEventRecord(e1, st);
     SEMPYR_CHECK_LAUNCH();
     return 0;

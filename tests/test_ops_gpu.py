@@ -38,6 +38,8 @@ CONV_CASES = [
     (2, 3, 64, 64, 64, 3, 1, 1, 0, True),       # D stem (res): its input gradient runs on the same kernel
     (1, 5, 64, 68, 3, 3, 1, 1, 0, True),        # odd channel count, non-square image
     (1, 6, 64, 64, 4, 3, 1, 1, 0, False),       # 4 output rows
+    (1, 8, 16, 256, 3, 3, 1, 1, 0, True),       # width 256: one wave per image row, neighbour pixels by lane shifts
+    (1, 3, 16, 256, 8, 3, 1, 1, 0, True),       # ... and as an input gradient
 ]
 
 
