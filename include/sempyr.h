@@ -84,10 +84,11 @@ int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, const float*
 
 /* y[B,Cout,Ho,Wo] = act(conv(x, w) (+ bias[Cout] if bias != NULL)); act is a SEMPYR_ACT_* code applied in the
  * kernel epilogue (`conv -> LeakyReLU` of the critic stem discriminator.py:106-107, `conv -> Tanh` of the generator head
- * generator.py:116-120), slope the LeakyReLU slope. */
+ * generator.py:116-120), slope the LeakyReLU slope. y_pooled (optional, [B,Cout,Ho/2,Wo/2]) also receives
+ * AvgPool2d(2)(y) (discriminator.py:109), computed in the same epilogue when the launch is a single pass. */
 int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wpacked_fwd,
                       const int32_t* ktab_fwd_dev, const float* bias, int act, float slope, float* y,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      float* y_pooled, void* workspace, size_t workspace_bytes, void* stream);
 
 /* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a
  * ConvTranspose2d whose forward this is). With ups=1 the result is the gradient in the upsampled

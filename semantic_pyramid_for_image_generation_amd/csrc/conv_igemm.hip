@@ -53,6 +53,26 @@ struct FastDiv {
     }
 };
 
+// GEMM pixel index -> (sample, row, column) of the pixel grid.  `quad` order (used when the 2x2 average pool is fused into
+// the epilogue) numbers the four pixels of each pooling window consecutively, so a window sits in 4 adjacent lanes of the
+// accumulator layout and its sum is two DPP quad permutes.
+__device__ __forceinline__ void decode_pixel(int n, int QHW, int QW, int quad, int& b, int& qy, int& qx) {
+    if (quad) {
+        const int q = n & 3, t = n >> 2;
+        const int Wh = QW >> 1, HWh = QHW >> 2;
+        b = t / HWh;
+        const int r = t - b * HWh;
+        const int yh = r / Wh;
+        qy = 2 * yh + (q >> 1);
+        qx = 2 * (r - yh * Wh) + (q & 1);
+    } else {
+        b = n / QHW;
+        const int r = n - b * QHW;
+        qy = r / QW;
+        qx = r - qy * QW;
+    }
+}
+
 struct IgemmParams {
     const float* A;        // GATHER: packed weights [Kpad][Mpad]; WGRAD: gy [B][M][QH*QW]
     const float* X;        // gathered tensor
@@ -80,6 +100,7 @@ struct IgemmParams {
     int C;                 // channel count of the gathered tensor
     int x_bytes, a_bytes;  // sizes of the X and A operands (buffer-load bounds)
     int act; float slope;  // GATHER epilogue activation (applied with the bias, only when splits == 1)
+    float* Pool; int quad; // fused AvgPool2d(2) of the (activated) output: pooled tensor, quad pixel order on
 };
 
 // UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
@@ -187,10 +208,8 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
         const int n = n0 + n_local;
         const bool valid = n < pN;
         const int nn = valid ? n : 0;
-        const int b = nn / pQHW;
-        const int r = nn - b * pQHW;
-        const int qy = r / pQW;
-        const int qx = r - qy * pQW;
+        int b, qy, qx;
+        decode_pixel(nn, pQHW, pQW, p.quad, b, qy, qx);
         g_ybase = valid ? qy * p.SY : -(1 << 20);               // invalid column never passes the bound test
         g_xbase = qx * p.SX;
         g_off = b * p.XCHW;
@@ -404,11 +423,25 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (TN * 32) + j * 32 + l31;
             if (n >= pN) continue;
-            const int b = n / pQHW;
-            const int r = n - b * pQHW;
-            const int qy = r / pQW;
-            const int qx = r - qy * pQW;
+            int b, qy, qx;
+            decode_pixel(n, pQHW, pQW, p.quad, b, qy, qx);
             float* op = out + (size_t)b * p.OCHW + (qy * p.OSY + pOPY) * p.OW + qx * p.OSX + pOPX;
+            if (p.quad) {                                       // uniform: 2x2 window = lanes 4q..4q+3 (N % 4 == 0)
+                float* pp = p.Pool + (size_t)b * (p.OCHW >> 2) + (qy >> 1) * (p.OW >> 1) + (qx >> 1);
+                const bool lead = (n & 3) == 0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) {
+                        float v = acc[i][j][r16];
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+                        const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                        if (lead && m < p.M) pp[(size_t)m * (p.OHW >> 2)] = 0.25f * v;
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
@@ -1107,7 +1140,7 @@ static int run_splitk_reduce(const float* slabs, float* out, const float* bias, 
 
 extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
                                  const int32_t* ktab, const float* bias, int act, float slope, float* y,
-                                 void* ws, size_t ws_bytes, void* stream)
+                                 float* y_pooled, void* ws, size_t ws_bytes, void* stream)
 {
     sempyr_conv_plan pl;
     if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_FWD, &pl)) return rc;
@@ -1133,9 +1166,18 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = (int)(pl.wpack_floats * 4);
     if (splits == 1) { p.Out = y; p.bias = bias; p.slab_stride = 0; p.act = act; p.slope = slope; }
     else { p.Out = (float*)ws; p.bias = nullptr; p.slab_stride = out_numel; }
-    if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) return launch_rgb3x3(p, st);
-    if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
-    if (splits > 1) return run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st);
+    if (y_pooled && ((pl.Ho | pl.Wo) & 1)) SEMPYR_FAIL("conv fwd: pooled output needs even output height and width");
+    if (y_pooled && act == SEMPYR_ACT_TANH) SEMPYR_FAIL("conv fwd: pooled output is defined for ReLU-family activations");
+    const bool fused_pool = y_pooled && splits == 1 && d->Cout > 4;          // MFMA single-pass launch: pool in the epilogue
+    if (fused_pool) { p.Pool = y_pooled; p.quad = 1; }
+    int rc = 0;
+    if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) rc = launch_rgb3x3(p, st);
+    else rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st);
+    if (rc) return rc;
+    if (splits > 1)
+        if ((rc = run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st))) return rc;
+    if (y_pooled && !fused_pool)
+        return sempyr_pool2_down(y, nullptr, y_pooled, d->B * d->Cout, pl.Ho, pl.Wo, 0.25f, SEMPYR_ACT_NONE, 0.f, stream);
     return 0;
 }
 

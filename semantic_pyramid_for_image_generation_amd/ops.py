@@ -161,13 +161,13 @@ def _workspace(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0):
+def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None):
     mp = plan.mode(CONV_FWD)
     wp = _packed_weights(plan, w, CONV_FWD)
     y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device)
     ws = _workspace(mp.ws_bytes, x.device)
     check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(), _p(bias), act_kind, slope,
-                              y.data_ptr(), _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
+                              y.data_ptr(), _p(pooled), _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
     return y
 
 
@@ -219,18 +219,16 @@ class _ConvFwd(Function):
             bias = _req(bias, "conv bias")
         if act_kind == ACT_TANH and pool:
             raise _lib.SempyrError("conv2d: pooled output needs a ReLU-family (or no) activation")
-        y = _raw_conv_fwd(plan, x, w, bias, act_kind, slope)
+        out = None
+        if pool:
+            out = torch.empty((plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2), dtype=torch.float32, device=x.device)
+        y = _raw_conv_fwd(plan, x, w, bias, act_kind, slope, out)
         ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None)
         ctx.plan = plan
         ctx.has_bias = bias is not None
         ctx.act = (act_kind, slope)
         ctx.pool = pool
-        if not pool:
-            return y
-        out = torch.empty((plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2), dtype=torch.float32, device=x.device)
-        check(L.sempyr_pool2_down(y.data_ptr(), 0, out.data_ptr(), plan.B * plan.Cout, plan.Ho, plan.Wo, 0.25, ACT_NONE, 0.0,
-                                  _stream()), "sempyr_pool2_down")
-        return out
+        return out if pool else y
 
     @staticmethod
     def backward(ctx, gy):
