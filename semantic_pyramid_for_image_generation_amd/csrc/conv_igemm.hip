@@ -22,6 +22,7 @@
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 // The gather table is read-only for the lifetime of a launch.  Reading it through the constant address space makes
 // its wave-uniform reads scalar loads; as plain global loads hipcc turns every read after the first workgroup barrier
 // into a per-lane vector load (a barrier counts as a possible clobber), i.e. a dependent memory round trip in front of
@@ -100,6 +101,7 @@ struct IgemmParams {
     int C;                 // channel count of the gathered tensor
     int x_bytes, a_bytes;  // sizes of the X and A operands (buffer-load bounds)
     int act; float slope;  // GATHER epilogue activation (applied with the bias, only when splits == 1)
+    int PR, PW, CW;        // patch kernel: patch rows / columns (source pixels), tile width in output pixels
     float* Pool; int quad; // fused AvgPool2d(2) of the (activated) output: pooled tensor, quad pixel order on
 };
 
@@ -476,6 +478,229 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
                         const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
                         if (m < p.M) out[(size_t)m * p.ldc + n] = acc[i][j][r16];
                     }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions (FWD incl. fused x2 upsample, and their DGRAD): the input patch of a tile is staged
+// in LDS ONCE per group of PCG channels and the nine taps read it as shifted views, instead of gathering a fresh
+// [16 x BN] operand tile per (tap, 16 channels).  A tile is BN consecutive output pixels = R full image rows (or a row
+// segment), so its patch is (R + 2) x (CW + 2) source pixels ((R/2 + 2) x (CW/2 + 2) through the upsample); per 8 channels
+// a thread issues ~24 gathers (8 with the upsample) where the generic kernel issues 72, and as many fewer LDS stores.
+// MFMA operand reads stay conflict-free: the 32 lanes of an operand read consecutive patch dwords (pairs of lanes the
+// same dword through the upsample = broadcast).  Per-lane patch offsets of the 9 taps are computed once per tile.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int PCG = 8;                                      // channels per staged patch
+
+template <int BM, int BN, int WM, int WN, int NSP>
+__global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmParams p)
+{
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_FLOATS = 9 * PCG * BM;
+    constexpr int A_V4 = A_FLOATS / 4, A_PER = (A_V4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* const As = psm;                                  // [tap][channel in group][m]
+    float* const Ps = psm + A_FLOATS;                       // [channel in group][PITCH >= patch rows x cols]
+    constexpr int PITCH = NSP * 256;                        // compile-time channel pitch: k-step offsets fold into the
+                                                            // ds_read immediate
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    const int MT = p.Mpad / BM;
+    int id = blockIdx.x, split = 0, m_tile, n_tile;
+    if (p.nsplits > 1) {
+        split = id % p.nsplits; id /= p.nsplits;
+        m_tile = id % MT; n_tile = id / MT;
+    } else {
+        const int xcd = id & 7; id >>= 3;
+        m_tile = id % MT;
+        n_tile = (id / MT) * 8 + xcd;
+    }
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    if (n0 >= p.N) return;                                  // uniform (N % BN == 0: no ragged tile)
+
+    // tile geometry (uniform): first output pixel, patch origin in source coordinates
+    const int tb = n0 / p.QHW;
+    const int tr = n0 - tb * p.QHW;
+    const int gy0 = tr / p.QW, gx0 = tr - gy0 * p.QW;
+    const int s = p.ups;
+    const int pr0 = (gy0 - 1) >> s, pc0 = (gx0 - 1) >> s;
+    const int PW = p.PW, PRPW = p.PR * p.PW;
+    const int XH = p.GH >> s;
+    const ctab_ptr ctab = (ctab_ptr)p.ktab;
+    const int C = p.C;
+
+    // per-lane patch offsets (floats, < 2^16) of the 9 taps for the lane's TN operand columns (+ the k-half of the
+    // lane), two columns per register
+    static_assert(TN <= 2, "tap offsets are packed two per register");
+    unsigned off[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int pk = ctab[2 * (t * C) + 1];               // packed dy/dx of tap t (uniform)
+        const int dy = pk >> 16, dx = (int)(short)(pk & 0xffff);
+        unsigned packed = 0u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * (TN * 32) + j * 32 + l31;
+            const int r = nl / p.CW, c = nl - r * p.CW;
+            const int o = (((gy0 + r + dy) >> s) - pr0) * PW + (((gx0 + c + dx) >> s) - pc0) + kh * PITCH;
+            packed |= (unsigned)o << (16 * j);
+        }
+        off[t] = packed;
+    }
+
+    // patch loads: thread owns NSP spatial patch positions, every channel of the group is one SGPR offset further
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    unsigned pvoff[NSP];
+#pragma unroll
+    for (int i = 0; i < NSP; ++i) {
+        const int pos = tid + 256 * i;
+        const int pr = pos / PW, pc = pos - pr * PW;
+        const int sy = pr0 + pr, sx = pc0 + pc;
+        const bool ok = pos < PRPW && (unsigned)sy < (unsigned)XH && (unsigned)sx < (unsigned)p.XW;   // else: zero-filled
+        pvoff[i] = ok ? 4u * (unsigned)(tb * p.XCHW + sy * p.XW + sx) : OOB;
+    }
+    int a_off[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int idx = tid + i * 256;
+        const int idc = idx < A_V4 ? idx : idx - A_V4;      // the surplus threads of the last slot re-read slot 0's data
+        const int t = idc / (PCG * BM / 4), rem = idc - t * (PCG * BM / 4);
+        const int kk = rem / (BM / 4), c4 = rem - kk * (BM / 4);
+        a_off[i] = (t * C + kk) * p.Mpad + m0 + c4 * 4;
+    }
+
+    const int ngroups = C / PCG;
+    const int gps = (ngroups + p.nsplits - 1) / p.nsplits;
+    const int g_begin = split * gps, g_end = min(g_begin + gps, ngroups);
+
+    float rp[NSP][PCG];
+    f32x4 ra[A_PER];
+    auto load_group = [&](int g) {
+        const float* ab = p.A + (size_t)g * PCG * p.Mpad;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ab + a_off[i]);
+        const int cb = g * PCG * p.XHW * 4;
+#pragma unroll
+        for (int i = 0; i < NSP; ++i)
+#pragma unroll
+            for (int ci = 0; ci < PCG; ++ci)
+                rp[i][ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (int)pvoff[i], cb + ci * p.XHW * 4, 0));
+    };
+    auto store_group = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+            if (tid + i * 256 < A_V4) *reinterpret_cast<f32x4*>(As + (tid + i * 256) * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) {
+            const int pos = tid + 256 * i;
+            if (pos < PRPW) {
+#pragma unroll
+                for (int ci = 0; ci < PCG; ++ci) Ps[ci * PITCH + pos] = rp[i][ci];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (g_begin < g_end) {
+        load_group(g_begin);
+        store_group();
+        __syncthreads();
+        const float* as = As + kh * BM + wm * (TM * 32) + l31;
+        for (int g = g_begin; g < g_end; ++g) {
+            const bool more = (g + 1) < g_end;
+            if (more) load_group(g + 1);                    // in flight under the 144 MFMAs of this group
+            __builtin_amdgcn_sched_barrier(0);
+            // 36 k-steps (9 taps x 4); the operands of step st+1 are read before the MFMAs of step st issue
+            constexpr int NST = 9 * (PCG / 2);
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = Ps[(off[0] >> (16 * j)) & 0xffffu];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < NST) {
+                    const int t = (st + 1) / (PCG / 2), ks = (st + 1) % (PCG / 2);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = as[(t * PCG + ks * 2) * BM + i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = Ps[((off[t] >> (16 * j)) & 0xffffu) + ks * 2 * PITCH];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                if (st + 1 < NST) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                // every wave is done reading this group's patch
+            if (more) { store_group(); __syncthreads(); }
+        }
+    }
+
+    // epilogue (as the generic kernel's GATHER epilogue)
+    float* out = p.Out + (size_t)split * p.slab_stride;
+    const bool full_m = (m0 + BM) <= p.M;
+    if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float bv[16];
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                bv[r16] = p.bias[m < p.M ? m : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] += bv[r16];
+        }
+    }
+    if (p.act != SEMPYR_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] = act_apply(acc[i][j][r16], p.act, p.slope);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+        const int r = n - tb * p.QHW;                        // the tile lies inside sample tb
+        float* op = out + (size_t)tb * p.OCHW + r;           // stride-1 output: OHW == QHW, pixel r of the plane
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+            if (full_m) {
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) op[(size_t)(mb + (r16 & 3) + 8 * (r16 >> 2)) * p.OHW] = acc[i][j][r16];
+            } else {
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                    if (m < p.M) op[(size_t)m * p.OHW] = acc[i][j][r16];
                 }
             }
         }
@@ -983,6 +1208,69 @@ int launch_rgb3x3(const IgemmParams& p, hipStream_t st) {
     return 0;
 }
 
+// Patch-kernel eligibility for a GATHER launch (FWD or stride-1 DGRAD) with tile width bn.  On success fills PR/PW/CW.
+inline bool patch3x3_ok(const sempyr_conv_desc* d, int mode, int bm, int bn, IgemmParams& p) {
+    const int C = mode == SEMPYR_CONV_FWD ? d->Cin : d->Cout;
+    const int M = mode == SEMPYR_CONV_FWD ? d->Cout : d->Cin;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || C % PCG != 0 || M <= 4) return false;
+    if (mode == SEMPYR_CONV_DGRAD && d->ups) return false;
+    if (p.Mpad % bm != 0 || p.N % bn != 0 || p.QHW % bn != 0) return false;      // tiles are whole and inside one sample
+    int R, CW;
+    if (bn % p.QW == 0) { R = bn / p.QW; CW = p.QW; }
+    else if (p.QW % bn == 0) { R = 1; CW = bn; }
+    else return false;
+    const int s = p.ups;
+    if (s && ((CW & 1) || (R > 1 && (R & 1)))) return false;
+    const int PR = s ? (R >= 2 ? R / 2 + 2 : 2) : R + 2;
+    const int PW = s ? CW / 2 + 2 : CW + 2;
+    if (PR * PW > 1024) return false;
+    const int nsp = PR * PW <= 512 ? 2 : 4;
+    if ((9 * PCG * bm + PCG * nsp * 256) * 4 > 160 * 1024 / 3) return false;     // 3 workgroups per CU
+    p.PR = PR; p.PW = PW; p.CW = CW;
+    return true;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_patch(const IgemmParams& p, int splits, hipStream_t st) {
+    const int MT = p.Mpad / BM, NT = p.N / BN;
+    IgemmParams pp = p; pp.nsplits = splits; pp.nphases = 1;
+    const int NT8 = (NT + 7) / 8 * 8;
+    dim3 grid(splits > 1 ? MT * NT * splits : MT * NT8, 1, 1);
+    const int nsp = p.PR * p.PW <= 512 ? 2 : 4;
+    const size_t lds = (size_t)(9 * PCG * BM + PCG * nsp * 256) * sizeof(float);
+    const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_prof.on) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.used + 2 <= g_prof.events.size()) {
+            e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
+            g_prof.used += 2;
+            g_prof.flops += flops;
+            g_prof.recs.push_back({10, BM, BN, p.M, p.N, p.K, splits, 1, flops});
+        }
+    }
+    if (e0) (void)hipEventRecord(e0, st);
+    if (p.PR * p.PW <= 512) hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, st, pp);
+    else hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), lds, st, pp);
+    if (e1) (void)hipEventRecord(e1, st);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+// returns 1 if the launch was taken by the patch kernel, 0 if not eligible, < 0 / hipError on failure
+int try_patch(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int splits, hipStream_t st) {
+    static const int enabled = env_int("SEMPYR_PATCH", 1);
+    if (!enabled) return 0;
+    int bm, bn; cfg_dims(cfg, bm, bn);
+    if (cfg != CFG_128x128 && cfg != CFG_64x256 && cfg != CFG_64x64) return 0;
+    if (!patch3x3_ok(d, mode, bm, bn, p)) return 0;
+    int rc;
+    if (cfg == CFG_128x128) rc = launch_patch<128, 128, 2, 2>(p, splits, st);
+    else if (cfg == CFG_64x256) rc = launch_patch<64, 256, 1, 4>(p, splits, st);
+    else rc = launch_patch<64, 64, 2, 2>(p, splits, st);
+    return rc ? rc : 1;
+}
+
 template <int MODE>
 int launch_cfg(int cfg, const IgemmParams& p, int splits, bool uniform_tap, hipStream_t st) {
     if (MODE == MODE_GATHER && p.M <= 4 && splits == 1) return launch_small_m(p, uniform_tap, st);
@@ -1172,7 +1460,11 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     if (fused_pool) { p.Pool = y_pooled; p.quad = 1; }
     int rc = 0;
     if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) rc = launch_rgb3x3(p, st);
-    else rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st);
+    else {
+        rc = fused_pool ? 0 : try_patch(d, SEMPYR_CONV_FWD, pl.cfg, p, splits, st);
+        if (rc == 0) rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st);
+        else if (rc == 1) rc = 0;
+    }
     if (rc) return rc;
     if (splits > 1)
         if ((rc = run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st))) return rc;
@@ -1241,7 +1533,10 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
         p.C = d->Cout;
         p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = (int)(pl.wpack_floats * 4);
         if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_DGRAD)) return launch_rgb3x3(p, st);
-        if (int rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cout % BK == 0, st)) return rc;
+        int rc = p.nphases == 1 ? try_patch(d, SEMPYR_CONV_DGRAD, pl.cfg, p, splits, st) : 0;
+        if (rc == 0) rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cout % BK == 0, st);
+        else if (rc == 1) rc = 0;
+        if (rc) return rc;
     }
     if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, SEMPYR_ACT_NONE, 0.f, st);
     return 0;
