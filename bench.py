@@ -215,7 +215,7 @@ def main():
                     traffic = json.load(f).get("traffic_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                               "kernel": "igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv fwd/dgrad/wgrad)",
+                               "kernel": "implicit-GEMM conv kernels on fp32 v_mfma_f32_32x32x2_f32 (igemm_kernel fwd/dgrad/wgrad, patch3x3_kernel; incl. the VALU RGB-head launches)",
                                "launches": int(kl.value), "avg_launch_us": 1000.0 * kms.value / kl.value,
                                "kernel_ms_total": kms.value, "kernel_time_share": kms.value * 1e-3 / elapsed,
                                "flops_per_cycle_survey": cycle_flops, "flops_counted_2MNK": kf.value,

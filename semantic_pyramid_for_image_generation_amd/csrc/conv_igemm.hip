@@ -1224,7 +1224,7 @@ inline bool patch3x3_ok(const sempyr_conv_desc* d, int mode, int bm, int bn, Ige
     const int PR = s ? (R >= 2 ? R / 2 + 2 : 2) : R + 2;
     const int PW = s ? CW / 2 + 2 : CW + 2;
     if (PR * PW > 1024) return false;
-    const int nsp = PR * PW <= 512 ? 2 : 4;
+    const int nsp = (PR * PW + 255) / 256 < 2 ? 2 : (PR * PW + 255) / 256;
     if ((9 * PCG * bm + PCG * nsp * 256) * 4 > 160 * 1024 / 3) return false;     // 3 workgroups per CU
     p.PR = PR; p.PW = PW; p.CW = CW;
     return true;
@@ -1236,7 +1236,7 @@ int launch_patch(const IgemmParams& p, int splits, hipStream_t st) {
     IgemmParams pp = p; pp.nsplits = splits; pp.nphases = 1;
     const int NT8 = (NT + 7) / 8 * 8;
     dim3 grid(splits > 1 ? MT * NT * splits : MT * NT8, 1, 1);
-    const int nsp = p.PR * p.PW <= 512 ? 2 : 4;
+    const int nsp = (p.PR * p.PW + 255) / 256 < 2 ? 2 : (p.PR * p.PW + 255) / 256;
     const size_t lds = (size_t)(9 * PCG * BM + PCG * nsp * 256) * sizeof(float);
     const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1250,7 +1250,8 @@ int launch_patch(const IgemmParams& p, int splits, hipStream_t st) {
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
-    if (p.PR * p.PW <= 512) hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, st, pp);
+    if (nsp == 2) hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, st, pp);
+    else if (nsp == 3) hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, st, pp);
     else hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), lds, st, pp);
     if (e1) (void)hipEventRecord(e1, st);
     SEMPYR_CHECK_LAUNCH();
@@ -1261,12 +1262,22 @@ int launch_patch(const IgemmParams& p, int splits, hipStream_t st) {
 int try_patch(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int splits, hipStream_t st) {
     static const int enabled = env_int("SEMPYR_PATCH", 1);
     if (!enabled) return 0;
+    if (cfg == CFG_64x256 && splits == 1) {                  // 64-row problems: narrower tiles when that evens out the rounds
+        // 64x256 tiles run 3 per CU (768 at a time), 64x128 tiles 4 per CU (1024): take the shape whose last round is
+        // fuller (N = 2^18: 1024 tiles = 1.33 rounds vs 2048 = 2.0 rounds; measured 0.204 -> 0.179 ms)
+        static const int force = env_int("SEMPYR_PATCH_BN", 0);
+        const long long t256 = (long long)(p.Mpad / 64) * (p.N / 256), t128 = 2 * t256;
+        const double e256 = (double)t256 / (double)((t256 + 767) / 768 * 768);
+        const double e128 = (double)t128 / (double)((t128 + 1023) / 1024 * 1024);
+        if (force == 128 || (force == 0 && p.N % 256 == 0 && e128 > e256 + 0.15)) cfg = CFG_64x128;
+    }
     int bm, bn; cfg_dims(cfg, bm, bn);
-    if (cfg != CFG_128x128 && cfg != CFG_64x256 && cfg != CFG_64x64) return 0;
+    if (cfg != CFG_128x128 && cfg != CFG_64x256 && cfg != CFG_64x64 && cfg != CFG_64x128) return 0;
     if (!patch3x3_ok(d, mode, bm, bn, p)) return 0;
     int rc;
     if (cfg == CFG_128x128) rc = launch_patch<128, 128, 2, 2>(p, splits, st);
     else if (cfg == CFG_64x256) rc = launch_patch<64, 256, 1, 4>(p, splits, st);
+    else if (cfg == CFG_64x128) rc = launch_patch<64, 128, 2, 2>(p, splits, st);
     else rc = launch_patch<64, 64, 2, 2>(p, splits, st);
     return rc ? rc : 1;
 }
