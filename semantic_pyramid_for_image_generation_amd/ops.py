@@ -368,6 +368,9 @@ def _norm_stats(x, gamma, beta, kind, eps, bn_state):
     check(L.sempyr_norm_stats(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(),
                               _p(rm), _p(rv), _p(nbt), momentum, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
           "sempyr_norm_stats")
+    if bn_state is not None:      # the kernel updated the buffers through raw pointers: tell version-keyed caches
+        torch.autograd.graph.increment_version(rm)
+        torch.autograd.graph.increment_version(rv)
     return rowbuf
 
 
@@ -539,8 +542,21 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, N):
 
 def bn_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, res=None, act_kind=ACT_NONE, slope=0.0):
     """Eval-mode BatchNorm2d (+ residual add + activation) with frozen statistics and parameters
-    (ResNet18 classifier, classifier.py:34 under .eval(); generator under `sample`, train_model.py:153)."""
-    coeffs = bn_eval_coeffs(_req(gamma), _req(beta), _req(running_mean), _req(running_var), eps, x.shape[0])
+    (ResNet18 classifier, classifier.py:34 under .eval(); generator under `sample`, train_model.py:153).
+    The per-row coefficients only change when a parameter / buffer does, so they are cached on the weight tensor
+    (keyed by batch size and tensor versions): the frozen classifier computes them once."""
+    N = x.shape[0]
+    key = (N, eps, gamma._version, beta._version, running_mean._version, running_var._version,
+           gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr())
+    hit = getattr(gamma, "_sempyr_bn_eval", None)
+    if hit is not None and hit[0] == key:
+        coeffs = hit[1]
+    else:
+        coeffs = bn_eval_coeffs(_req(gamma), _req(beta), _req(running_mean), _req(running_var), eps, N)
+        try:
+            gamma._sempyr_bn_eval = (key, coeffs)
+        except Exception:  # pragma: no cover
+            pass
     return _AffineRowAct.apply(x, res, coeffs, act_kind, slope)
 
 
