@@ -7,6 +7,7 @@ expressed with differentiable Functions, so the WGAN-GP double backward
 discriminator uses.  There is no CPU path: non-CUDA(HIP) tensors raise.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -20,7 +21,7 @@ L = _lib.lib
 
 __all__ = ["conv2d", "conv_transpose2d", "norm_act", "norm_add_norm_act", "bn_eval_act", "act", "add_act", "mul", "normalize",
            "avg_pool2", "upsample2", "max_pool3s2", "global_avg_pool", "mean", "l1_mean", "gp_loss", "lerp_rows",
-           "input_grads_only", "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_TANH", "NORM_BATCH", "NORM_INSTANCE",
+           "input_grads_only", "async_param_grads", "join_side_streams", "ACT_NONE", "ACT_RELU", "ACT_LRELU", "ACT_TANH", "NORM_BATCH", "NORM_INSTANCE",
            "NORM_LAYER"]
 
 
@@ -62,6 +63,77 @@ class input_grads_only:
     def __exit__(self, *exc):
         global _INPUT_GRADS_ONLY
         _INPUT_GRADS_ONLY = self._prev
+
+
+# Weight / bias gradients are leaves of the backward pass: nothing downstream waits for them until the optimizer
+# step.  Inside `with async_param_grads():` they are computed on a second HIP stream and accumulated straight into
+# `param.grad`, so the MFMA-bound WGRAD kernels overlap the HBM-bound normalisation / activation backward and the input-
+# gradient chain on the main stream.  Leaving the block makes the current stream wait for the side stream.  Only plain
+# backward passes (no create_graph) take this route; SEMPYR_ASYNC_WGRAD=0 turns it off.
+_ASYNC_ENV = os.environ.get("SEMPYR_ASYNC_WGRAD", "1") != "0"
+_ASYNC_ON = False
+_SIDE = {}
+_SIDE_DIRTY = set()
+
+
+def _side_stream(device):
+    s = _SIDE.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE[device.index] = s
+    return s
+
+
+def join_side_streams():
+    for idx in list(_SIDE_DIRTY):
+        torch.cuda.current_stream(idx).wait_stream(_SIDE[idx])
+    _SIDE_DIRTY.clear()
+
+
+class async_param_grads:
+    def __enter__(self):
+        global _ASYNC_ON
+        self._prev = _ASYNC_ON
+        _ASYNC_ON = _ASYNC_ENV
+        return self
+
+    def __exit__(self, *exc):
+        global _ASYNC_ON
+        _ASYNC_ON = self._prev
+        join_side_streams()
+
+
+def _is_leaf_param(t):
+    return t is not None and t.is_leaf and t.requires_grad
+
+
+def _accumulate_grad(param, g, main):
+    g.record_stream(main)                 # allocated on the side stream, consumed by the optimizer on the main one
+    if param.grad is None:
+        param.grad = g
+    else:
+        param.grad.add_(g)
+
+
+def _param_grads_async(gy, x, plan, w, bias, want_w, want_b):
+    """WGRAD(gy, x) -> w.grad and channel_sum(gy) -> bias.grad on the side stream."""
+    dev = gy.device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        if want_w:
+            _accumulate_grad(w, _raw_conv_wgrad(plan, gy, x), main)
+        if want_b:
+            _accumulate_grad(bias, _channel_sum_raw(gy), main)
+    gy.record_stream(side)
+    x.record_stream(side)
+    _SIDE_DIRTY.add(dev.index)
+
+
+def _can_async(w, bias, want_w, want_b):
+    return (_ASYNC_ON and not torch.is_grad_enabled() and (want_w or want_b)
+            and (not want_w or _is_leaf_param(w)) and (not want_b or _is_leaf_param(bias)))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -223,7 +295,7 @@ class _ConvFwd(Function):
         if pool:
             out = torch.empty((plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2), dtype=torch.float32, device=x.device)
         y = _raw_conv_fwd(plan, x, w, bias, act_kind, slope, out)
-        ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None)
+        ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None, bias)
         ctx.plan = plan
         ctx.has_bias = bias is not None
         ctx.act = (act_kind, slope)
@@ -232,7 +304,7 @@ class _ConvFwd(Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, bias = ctx.saved_tensors
         plan = ctx.plan
         gy = gy.contiguous()
         if ctx.pool:
@@ -240,13 +312,18 @@ class _ConvFwd(Function):
         elif y is not None:
             gy = _ActBwd.apply(gy, y, *ctx.act)
         gx = gw = gb = None
+        if not _INPUT_GRADS_ONLY:
+            want_w = ctx.needs_input_grad[1]
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            if _can_async(w, bias, want_w, want_b):
+                _param_grads_async(gy, x, plan, w, bias, want_w, want_b)     # issued first: overlaps the input gradient
+            else:
+                if want_w:
+                    gw = _ConvWgrad.apply(gy, x, plan)
+                if want_b:
+                    gb = _bias_grad(gy)
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(gy, w, plan)
-        if not _INPUT_GRADS_ONLY:
-            if ctx.needs_input_grad[1]:
-                gw = _ConvWgrad.apply(gy, x, plan)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = _bias_grad(gy)
         return gx, gw, gb, None, None, None, None
 
 
@@ -266,24 +343,29 @@ class _ConvDgrad(Function):
         gy = _req(gy, "dgrad input"); w = _req(w, "conv weight")
         if bias is not None:
             bias = _req(bias, "bias")
-        ctx.save_for_backward(gy, w)
+        ctx.save_for_backward(gy, w, bias)
         ctx.plan = plan
         ctx.has_bias = bias is not None
         return _raw_conv_dgrad(plan, gy, w, bias)
 
     @staticmethod
     def backward(ctx, u):
-        gy, w = ctx.saved_tensors
+        gy, w, bias = ctx.saved_tensors
         plan = ctx.plan
         u = u.contiguous()
         g_gy = g_w = g_b = None
+        if not _INPUT_GRADS_ONLY:
+            want_w = ctx.needs_input_grad[1]
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            if _can_async(w, bias, want_w, False) and not want_b:
+                _param_grads_async(gy, u, plan, w, None, want_w, False)
+            else:
+                if want_w:
+                    g_w = _ConvWgrad.apply(gy, u, plan)
+                if want_b:
+                    g_b = _bias_grad(u)
         if ctx.needs_input_grad[0]:
             g_gy = _ConvFwd.apply(u, w, None, plan)
-        if not _INPUT_GRADS_ONLY:
-            if ctx.needs_input_grad[1]:
-                g_w = _ConvWgrad.apply(gy, u, plan)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                g_b = _bias_grad(u)
         return g_gy, g_w, g_b, None
 
 

@@ -7,7 +7,7 @@ import time
 import torch
 import torch.optim as optim
 
-from . import parallel
+from . import ops, parallel
 from .featuresCreatorGen import Features1ToImage, FeaturesDiscriminator, LevelUpFeaturesGenerator
 from .train_model import (L1Loss, Normalize, _frozen, get_wgan_losses_fn, gradient_penalty, load_classifier,
                           print_gpu_details)
@@ -35,7 +35,8 @@ def train_generator(features_gen, discriminator, classifier, features_gen_optimi
                              'next_level_loss': next_level_features_loss}
         total_loss = generator_loss + features_loss + 0.2 * next_level_features_loss
         features_gen.zero_grad()
-        total_loss.backward()
+        with ops.async_param_grads():
+            total_loss.backward()
     parallel.sync_gradients(features_gen)
     features_gen_optimizer.step()
     return losses_dictionary
@@ -55,7 +56,8 @@ def train_discriminator(features_gen, discriminator, discriminator_loss_fn, disc
     gp = gradient_penalty(discriminator, real, fake_features, alpha)
     discriminator_loss = (real_loss + fake_loss) + gp * args.gradient_penalty_weight
     discriminator.zero_grad()
-    discriminator_loss.backward()
+    with ops.async_param_grads():
+        discriminator_loss.backward()
     parallel.sync_gradients(discriminator)
     discriminator_optimizer.step()
     return {'d_loss': real_loss + fake_loss, 'gp': gp}

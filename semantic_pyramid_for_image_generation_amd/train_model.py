@@ -176,7 +176,8 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
             loses_dictionary['total loss'] = total_loss
 
         generator.zero_grad()
-        total_loss.backward()
+        with ops.async_param_grads():
+            total_loss.backward()
     parallel.sync_gradients(generator)
     generator_optimizer.step()
     return loses_dictionary
@@ -213,7 +214,8 @@ def train_discriminator(generator, discriminator, discriminator_loss_fn, discrim
     discriminator_loss = (real_images_d_loss + fake_images_d_loss) + gp * args.gradient_penalty_weight
 
     discriminator.zero_grad()
-    discriminator_loss.backward()
+    with ops.async_param_grads():
+        discriminator_loss.backward()
     parallel.sync_gradients(discriminator)
     discriminator_optimizer.step()
     return {'d_loss': real_images_d_loss + fake_images_d_loss, 'gp': gp}
