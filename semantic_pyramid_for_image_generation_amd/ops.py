@@ -103,6 +103,26 @@ class async_param_grads:
         join_side_streams()
 
 
+TWO_STREAM_CRITIC = os.environ.get("SEMPYR_TWO_STREAM", "1") != "0"
+TWO_STREAM_GENERATOR = os.environ.get("SEMPYR_TWO_STREAM_G", "1") != "0"
+
+
+def side_stream(device):
+    """The library's second stream on `device` (independent branches of a step may run there, see train_discriminator)."""
+    return _side_stream2(device)
+
+
+_SIDE2 = {}
+
+
+def _side_stream2(device):
+    s = _SIDE2.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE2[device.index] = s
+    return s
+
+
 def _is_leaf_param(t):
     return t is not None and t.is_leaf and t.requires_grad
 
@@ -218,12 +238,19 @@ def _packed_weights(plan, w, mode):
         if cache is not None:
             hit = cache.get(wkey)
             if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
+                cur = torch.cuda.current_stream(w.device)
+                if hit[4] != cur.cuda_stream:          # packed on another stream: order this stream after the pack kernel
+                    cur.wait_event(hit[3])
+                    hit[1].record_stream(cur)
                 return hit[1]
     wp = torch.empty(max(int(mp.info.wpack_floats), 1), dtype=torch.float32, device=w.device)
     check(L.sempyr_conv2d_pack_weights(plan.desc_ref, mode, w.data_ptr(), mp.wsrc.data_ptr(), wp.data_ptr(), _stream()),
           "sempyr_conv2d_pack_weights")
     if cache is not None:
-        cache[wkey] = (w._version, wp, w.data_ptr())
+        cur = torch.cuda.current_stream(w.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        cache[wkey] = (w._version, wp, w.data_ptr(), ev, cur.cuda_stream)
     return wp
 
 

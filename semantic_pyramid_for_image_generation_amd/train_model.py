@@ -22,6 +22,11 @@ from .classifier import Classifier  # noqa: F401
 from .discriminator import Discriminator
 from .generator import Generator
 
+# branches of a step run on two streams (train_discriminator / train_generator): the parameter-gradient accumulation
+# nodes then see gradients from both, which is intended
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 args = None     # set by the CLI (or by the caller): needs .use_diversity_loss and .gradient_penalty_weight
 
 
@@ -157,11 +162,25 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
 
     with _frozen(discriminator, classifier):
         fake_images = generator(z, features, masks)
-        generator_loss = generator_loss_fn(discriminator(fake_images))
+        two_stream = ops.TWO_STREAM_GENERATOR and fake_images.is_cuda
+        if two_stream:
+            # the critic branch and the classifier-feature branch only share fake_images: two streams (forward and, through
+            # the autograd engine, backward), joined before the losses are summed
+            main = torch.cuda.current_stream(device)
+            side = ops.side_stream(device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                generator_loss = generator_loss_fn(discriminator(fake_images))
+            fake_images.record_stream(side)
+        else:
+            generator_loss = generator_loss_fn(discriminator(fake_images))
 
         fake_images_clf = normalizer_clf(fake_images)
         _, fake_features = classifier(fake_images_clf)
         features_loss = getLossByTrainType(features, masks, train_type, features_to_train, fake_features, criterion_features)
+        if two_stream:
+            main.wait_stream(side)
+            generator_loss.record_stream(main)
 
         total_loss = generator_loss + features_loss
         loses_dictionary = {'g_loss': generator_loss, 'features_loss': features_loss, 'total_loss': total_loss}
@@ -199,17 +218,31 @@ def train_discriminator(generator, discriminator, discriminator_loss_fn, discrim
     with torch.no_grad():                                                 # reference: forward with graph, then .detach()
         fake_images = generator(z, features, masks)
 
-    if _samplewise(discriminator):
-        # no layer mixes samples (instance / layer norm or none): one pass over both batches gives the same logits as the
-        # reference's two passes and fills the small late layers twice as well
-        n = real_images.shape[0]
-        logits = discriminator(torch.cat([real_images, fake_images]))
-        real_images_d_logit, fake_images_d_logit = logits[:n], logits[n:]
+    def logits_loss():
+        if _samplewise(discriminator):
+            # no layer mixes samples (instance / layer norm or none): one pass over both batches gives the same logits as
+            # the reference's two passes and fills the small late layers twice as well
+            n = real_images.shape[0]
+            logits = discriminator(torch.cat([real_images, fake_images]))
+            return discriminator_loss_fn(logits[:n], logits[n:])
+        return discriminator_loss_fn(discriminator(real_images), discriminator(fake_images))
+
+    if ops.TWO_STREAM_CRITIC and real_images.is_cuda:
+        # the logit branch and the gradient-penalty branch share nothing but the weights: run them on two streams (the
+        # autograd engine replays each branch's backward on the stream of its forward), so their many mid-size kernels
+        # fill each other's idle CUs
+        main = torch.cuda.current_stream(device)
+        side = ops.side_stream(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            real_images_d_loss, fake_images_d_loss = logits_loss()
+        real_images.record_stream(side); fake_images.record_stream(side)
+        gp = gradient_penalty(discriminator, real_images, fake_images, alpha)
+        main.wait_stream(side)
+        real_images_d_loss.record_stream(main); fake_images_d_loss.record_stream(main)
     else:
-        real_images_d_logit = discriminator(real_images)
-        fake_images_d_logit = discriminator(fake_images)
-    real_images_d_loss, fake_images_d_loss = discriminator_loss_fn(real_images_d_logit, fake_images_d_logit)
-    gp = gradient_penalty(discriminator, real_images, fake_images, alpha)
+        real_images_d_loss, fake_images_d_loss = logits_loss()
+        gp = gradient_penalty(discriminator, real_images, fake_images, alpha)
 
     discriminator_loss = (real_images_d_loss + fake_images_d_loss) + gp * args.gradient_penalty_weight
 
