@@ -33,11 +33,12 @@ def synthesize_batch(generator, classifier, images, normalizer_clf, num_levels=4
         out = {}
         for level in range(1, num_levels + 1):
             feats = one_level(features, level)
-            imgs = []
-            for i in range(num_noises):
-                z = noises[level - 1][i] if noises is not None else torch.randn(B, 128, 1, 1, device=device)
-                imgs.append(generator(z, feats, masks))
-            out[level] = torch.vstack(imgs)
+            zs = [noises[level - 1][i] if noises is not None else torch.randn(B, 128, 1, 1, device=device)
+                  for i in range(num_noises)]
+            # eval-mode BatchNorm: samples are independent, so the num_noises generator calls of the reference loop run as
+            # ONE batch of num_noises*B (same images in the same order, 4x fewer and 4x fuller launches)
+            rep = lambda t: t.repeat(num_noises, 1, 1, 1)
+            out[level] = generator(torch.cat(zs), [rep(f) for f in feats], [rep(m) for m in masks])
     return out
 
 
