@@ -219,3 +219,36 @@ def test_feature_gen_steps(dev):
         assert abs(float(gsd[k].double().norm()) - v) <= 2e-3 * max(1.0, v), ('G', k)
     for k, v in info['D_norms'].items():
         assert abs(float(dsd[k].double().norm()) - v) <= 2e-3 * max(1.0, v), ('D', k)
+
+
+def test_stream_overlap_matches_single_stream(dev):
+    """The two-stream critic step + side-stream weight gradients against the plain single-stream execution of the same
+    step (same weights, inputs, z, alpha) at batch 8: every gradient equal up to accumulation order, losses equal, and the
+    overlapped run repeated is bit-identical (a cross-stream race would show up as run-to-run differences)."""
+    from semantic_pyramid_for_image_generation_amd import ops
+    tm, G, D, C, tr, images, feats, masks, z, z2, alpha = _setup(dev, 'res', 'instance_norm', False, 77, B=8)
+    d_loss_fn, _ = tm.get_wgan_losses_fn()
+    state = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    args = (((images - 0.5) / 0.5).to(dev), [f.to(dev) for f in feats], [m.to(dev) for m in masks])
+
+    def run(overlap):
+        saved = (ops.TWO_STREAM_CRITIC, ops._ASYNC_ENV)
+        ops.TWO_STREAM_CRITIC = ops._ASYNC_ENV = overlap
+        try:
+            D.load_state_dict(state)
+            opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            out = tm.train_discriminator(G, D, d_loss_fn, opt, *args, z=z.to(dev), alpha=alpha.to(dev))
+            torch.cuda.synchronize()
+            return ({k: float(v) for k, v in out.items()}, {k: p.grad.detach().clone() for k, p in D.named_parameters()})
+        finally:
+            ops.TWO_STREAM_CRITIC, ops._ASYNC_ENV = saved
+    l1, g1 = run(True)
+    l2, g2 = run(True)
+    l0, g0 = run(False)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+        scale = float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= 1e-5 * max(scale, 1e-6), k
+    for k in l0:
+        assert l1[k] == l2[k]
+        assert abs(l1[k] - l0[k]) <= 1e-6 * max(1.0, abs(l0[k])), k
