@@ -202,7 +202,11 @@ def main():
 
     if rank == 0:
         iters = 5 * a.steps
-        cycle_flops = B * (5 * D_STEP_FLOPS + (G_STEP_DIV_FLOPS if a.use_diversity_loss else G_STEP_FLOPS))
+        # SURVEY 8d per-sample forward GFLOP: res F_G 19.053 / F_D 1.703, default F_G 2.921 / F_D 1.577, classifier 4.738
+        f_g, f_d = (F_G, F_D) if a.gen_type == 'res' else (2.921e9, 1.577e9)
+        d_step = F_C + f_g + 12 * f_d
+        g_step = (6 if a.use_diversity_loss else 3) * f_g + 2 * f_d + 2 * F_C
+        cycle_flops = B * (5 * d_step + g_step)
         out = {
             "metric": "WGAN-GP train loop iterations/sec (train_model.py loop body; 1 D step per iteration, 1 G step every 5)",
             "value": iters * world / elapsed, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

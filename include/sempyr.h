@@ -134,7 +134,7 @@ int sempyr_norm_bwd(int kind, const float* gy, const float* y, const float* x, c
                     float* scratch, void* stream);
 
 /* Backward of sempyr_norm_bwd's gx output: given u = dL/d(gx) returns dL/d(gy), dL/dx, dL/dgamma
- * (g_gamma may be NULL). scratch: 18*N*C floats. */
+ * (g_gamma may be NULL). scratch: 19*N*C floats. */
 int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, const float* y, const float* x,
                         const float* gamma, const float* mean_row, const float* rstd_row,
                         int N, int C, int HW, int act, float slope,

@@ -231,7 +231,13 @@ __global__ __launch_bounds__(256) void norm_bwd_rowsums_kernel(const float* __re
 }
 
 // group sums -> per-row coefficients of gx = cA*gy' + cB*(x - mean) + cC ; channel sums -> ggamma, gbeta (double math)
-__global__ void norm_bwd_finalize_kernel(int kind, const float* __restrict__ sums, int N, int C, int len,
+__device__ __forceinline__ double lpg_sum_d(double v) {
+#pragma unroll
+    for (int o = FIN_LPG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(int kind, const float* __restrict__ sums, int N, int C, int len,
                                          const float* __restrict__ gamma, const float* __restrict__ rstd_row,
                                          float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
                                          float* __restrict__ ggamma, float* __restrict__ gbeta)
@@ -242,26 +248,28 @@ __global__ void norm_bwd_finalize_kernel(int kind, const float* __restrict__ sum
     auto G1 = [&](int row) { return (double)sums[row] * len + (double)sums[rows + row]; };                        // sum gy'
     auto G2 = [&](int row) { return ((double)sums[3 * rows + row] + (double)sums[row] * (double)sums[2 * rows + row])
                                     * (double)rstd_row[row]; };                                                 // sum gy'*xhat
-    if (idx < ng) {
+    if (idx < ng * FIN_LPG) {                  // FIN_LPG lanes per group (a LAYER-norm group has up to 512 rows)
+        const int g = idx / FIN_LPG, l = idx % FIN_LPG;
         int start, stride, count;
-        group_rows(kind, idx, N, C, start, stride, count);
+        group_rows(kind, g, N, C, start, stride, count);
         double SA = 0.0, SB = 0.0;
-        for (int i = 0; i < count; ++i) {
+        for (int i = l; i < count; i += FIN_LPG) {
             const int row = start + i * stride;
             const double gm = gamma[row % C];
             SA += gm * G1(row); SB += gm * G2(row);
         }
+        SA = lpg_sum_d(SA); SB = lpg_sum_d(SB);
         const double m = (double)count * (double)len;
         const double abar = SA / m, sbar = SB / m;
-        for (int i = 0; i < count; ++i) {
+        for (int i = l; i < count; i += FIN_LPG) {
             const int row = start + i * stride;
             const double r = rstd_row[row];
             cA[row] = (float)(r * gamma[row % C]);
             cB[row] = (float)(-r * r * sbar);
             cC[row] = (float)(-r * abar);
         }
-    } else if (idx < ng + C) {
-        const int c = idx - ng;
+    } else if (idx < ng * FIN_LPG + C) {
+        const int c = idx - ng * FIN_LPG;
         double a = 0.0, b = 0.0;
         for (int n = 0; n < N; ++n) { a += G1(n * C + c); b += G2(n * C + c); }
         if (gbeta) gbeta[c] = (float)a;
@@ -379,27 +387,32 @@ __device__ __forceinline__ RowSums unshift(const float* __restrict__ sums, int r
     return o;
 }
 
-// coef layout [9][rows]: P1 P2 P3 Q1 Q2 Q3 Q4 ubar t      (double math; see the derivation in DESIGN.md)
-__global__ void norm_bwdbwd_finalize_kernel(int kind, const float* __restrict__ sums, int N, int C, int len,
+// coef layout [10][rows]: P1 P2 P3 Q1 Q2 Q3 Q4 ubar t (float) ; the group's ubar and t are also kept as double split into
+// (hi, lo) floats -- hi in slots 7/8, lo in sums slot 8 and coef slot 9 -- for the gamma-gradient kernel (double math; see
+// the derivation in DESIGN.md).  FIN_LPG lanes per group.
+__global__ __launch_bounds__(256) void norm_bwdbwd_finalize_kernel(int kind, float* __restrict__ sums, int N, int C, int len,
                                             const float* __restrict__ gamma, const float* __restrict__ rstd_row,
                                             float* __restrict__ coef)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= num_groups(kind, N, C)) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = idx / FIN_LPG, l = idx % FIN_LPG;
+    const bool live = g < num_groups(kind, N, C);
     const int rows = N * C;
-    int start, stride, count;
-    group_rows(kind, g, N, C, start, stride, count);
+    int start = 0, stride = 1, count = 0;
+    if (live) group_rows(kind, g, N, C, start, stride, count);
     double U = 0, T = 0, SA = 0, SB = 0, UA = 0;
-    for (int i = 0; i < count; ++i) {
+    for (int i = l; i < count; i += FIN_LPG) {
         const int row = start + i * stride;
         const double gm = gamma[row % C];
         const RowSums q = unshift(sums, rows, row, len, rstd_row[row]);
         U += q.r1; T += q.r2; SA += gm * q.r3; SB += gm * q.r4; UA += gm * q.r5;
     }
+    U = lpg_sum_d(U); T = lpg_sum_d(T); SA = lpg_sum_d(SA); SB = lpg_sum_d(SB); UA = lpg_sum_d(UA);
+    if (!live) return;
     const double m = (double)count * (double)len;
     const double ub = U / m, t = T / m, ab = SA / m, s = SB / m, mua = UA / m;
     const double w = mua - ub * ab - 3.0 * s * t;
-    for (int i = 0; i < count; ++i) {
+    for (int i = l; i < count; i += FIN_LPG) {
         const int row = start + i * stride;
         const double gm = gamma[row % C];
         const double r = rstd_row[row];
@@ -413,11 +426,14 @@ __global__ void norm_bwdbwd_finalize_kernel(int kind, const float* __restrict__ 
         coef[6 * rows + row] = (float)(r2 * (s * ub + t * ab));    // Q4
         coef[7 * rows + row] = (float)ub;
         coef[8 * rows + row] = (float)t;
+        sums[8 * rows + row] = (float)(ub - (double)(float)ub);
+        coef[9 * rows + row] = (float)(t - (double)(float)t);
     }
 }
 
-// g_gamma[c] = sum_n rstd * (sum u*gy' - ubar*sum gy' - t*sum gy'*xhat), with the group's ubar and t (double math)
-__global__ void norm_bwdbwd_ggamma_kernel(int kind, const float* __restrict__ sums, const float* __restrict__ gamma,
+// g_gamma[c] = sum_n rstd * (sum u*gy' - ubar*sum gy' - t*sum gy'*xhat), with the group's ubar and t from the finalize
+// kernel (double math)
+__global__ void norm_bwdbwd_ggamma_kernel(int kind, const float* __restrict__ sums, const float* __restrict__ coef,
                                           const float* __restrict__ rstd_row, int N, int C, int len,
                                           float* __restrict__ ggamma)
 {
@@ -427,19 +443,10 @@ __global__ void norm_bwdbwd_ggamma_kernel(int kind, const float* __restrict__ su
     double a = 0.0;
     for (int n = 0; n < N; ++n) {
         const int row = n * C + c;
-        // recompute the group's means in double (groups are small: N rows, 1 row or C rows)
-        const int g = kind == SEMPYR_NORM_BATCH ? c : (kind == SEMPYR_NORM_INSTANCE ? row : n);
-        int start, stride, count;
-        group_rows(kind, g, N, C, start, stride, count);
-        double U = 0, T = 0;
-        for (int i = 0; i < count; ++i) {
-            const int rr = start + i * stride;
-            const RowSums q = unshift(sums, rows, rr, len, rstd_row[rr]);
-            U += q.r1; T += q.r2;
-        }
-        const double m = (double)count * (double)len;
+        const double ub = (double)coef[7 * rows + row] + (double)sums[8 * rows + row];
+        const double t = (double)coef[8 * rows + row] + (double)coef[9 * rows + row];
         const RowSums q = unshift(sums, rows, row, len, rstd_row[row]);
-        a += (double)rstd_row[row] * (q.r5 - (U / m) * q.r3 - (T / m) * q.r4);
+        a += (double)rstd_row[row] * (q.r5 - ub * q.r3 - t * q.r4);
     }
     ggamma[c] = (float)a;
 }
@@ -548,8 +555,8 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     SEMPYR_CHECK_LAUNCH();
-    const int nthreads = num_groups(kind, N, C) + C;
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(nthreads, 64)), dim3(64), 0, st, kind, sums, N, C, HW, gamma,
+    const int nthreads = num_groups(kind, N, C) * FIN_LPG + C;
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(nthreads, 256)), dim3(256), 0, st, kind, sums, N, C, HW, gamma,
                        rstd_row, cA, cB, cC, ggamma, gbeta);
     SEMPYR_CHECK_LAUNCH();
     const long long total = (long long)rows * HW;
@@ -575,11 +582,11 @@ extern "C" int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, co
     if (HW >= 2048) hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     else hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     SEMPYR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(norm_bwdbwd_finalize_kernel, dim3(ceil_div(num_groups(kind, N, C), 64)), dim3(64), 0, st, kind, sums, N, C, HW,
-                       gamma, rstd_row, coef);
+    hipLaunchKernelGGL(norm_bwdbwd_finalize_kernel, dim3(ceil_div((long long)num_groups(kind, N, C) * FIN_LPG, 256)), dim3(256), 0, st,
+                       kind, sums, N, C, HW, gamma, rstd_row, coef);
     SEMPYR_CHECK_LAUNCH();
     if (g_gamma) {
-        hipLaunchKernelGGL(norm_bwdbwd_ggamma_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, kind, sums, gamma, rstd_row, N, C, HW, g_gamma);
+        hipLaunchKernelGGL(norm_bwdbwd_ggamma_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, kind, sums, coef, rstd_row, N, C, HW, g_gamma);
         SEMPYR_CHECK_LAUNCH();
     }
     const long long total = (long long)rows * HW;

@@ -585,7 +585,7 @@ class _NormActBwd(Function):
         g_x = torch.empty_like(x)
         want_param = ctx.needs_input_grad[3] and not _INPUT_GRADS_ONLY
         g_gamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param else None
-        scratch = torch.empty(18 * rows, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(19 * rows, dtype=torch.float32, device=x.device)
         check(L.sempyr_norm_bwd_bwd(kind, u.data_ptr(), gy.data_ptr(), _p(y), x.data_ptr(), gamma.data_ptr(),
                                     rowbuf.data_ptr(), rowbuf.data_ptr() + 4 * rows, N, C, HW, act_kind, slope,
                                     g_gy.data_ptr(), g_x.data_ptr(), _p(g_gamma), scratch.data_ptr(), _stream()),
