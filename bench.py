@@ -154,11 +154,14 @@ def main():
         cycle()
     timing = not a.no_kernel_timing
     barrier()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         cycle()
+    host_issue = time.perf_counter() - t0          # all launches issued (GPU may still be running)
     barrier()
     elapsed = time.perf_counter() - t0
+    cpu_time = time.process_time() - c0
     # Kernel durations for the roofline: the SAME K steps run once more with a HIP event pair around every conv launch
     # (recorded on the launch's own stream).  They are not recorded during the headline pass because an event pair per
     # launch keeps consecutive kernels from overlapping (measured: +4 % on the cycle time); `instrumented_ms_per_step`
@@ -212,6 +215,7 @@ def main():
             "value": iters * world / elapsed, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "host": {"issue_ms_per_step": 1000.0 * host_issue / a.steps, "cpu_time_per_step_ms": 1000.0 * cpu_time / a.steps},
             "config": {"workload": f"train_model.py cycle = 5 loop iterations (5 D steps + 1 G step), gen-type {a.gen_type}, "
                                    f"{a.discriminator_norm}, GP weight 10, batch {B}/GPU, 256x256"
                                    + (", diversity loss" if a.use_diversity_loss else ""),

@@ -202,6 +202,31 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
     return loses_dictionary
 
 
+_PINNED = {}
+
+
+def _cpu_randn_to(device, *shape):
+    """`torch.randn(*shape).to(device)` (same draws from the CPU generator as the reference, train_model.py:125) without
+    the host-device synchronisation of a pageable copy: the noise is drawn into one of a small ring of pinned buffers and
+    copied asynchronously; a buffer is reused only after the event recorded behind its last copy has completed."""
+    if device.type != 'cuda':
+        return torch.randn(*shape).to(device)
+    ring = _PINNED.setdefault((device.index, shape), {'bufs': [], 'next': 0})
+    if len(ring['bufs']) < 8:
+        ring['bufs'].append([torch.empty(shape, dtype=torch.float32).pin_memory(), None])
+        slot = ring['bufs'][-1]
+    else:
+        slot = ring['bufs'][ring['next']]
+        ring['next'] = (ring['next'] + 1) % len(ring['bufs'])
+        slot[1].synchronize()
+    torch.randn(shape, out=slot[0])
+    z = slot[0].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    slot[1] = ev
+    return z
+
+
 def _samplewise(module):
     """True when no submodule computes statistics across the batch (BatchNorm), i.e. f(cat(a, b)) == cat(f(a), f(b))."""
     return not any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in module.modules())
@@ -214,7 +239,7 @@ def train_discriminator(generator, discriminator, discriminator_loss_fn, discrim
     generator.train()
     discriminator.train()
     if z is None:
-        z = torch.randn(real_images.shape[0], 128, 1, 1).to(device)      # CPU generator, as in the reference (Q7)
+        z = _cpu_randn_to(device, real_images.shape[0], 128, 1, 1)        # CPU generator, as in the reference (Q7)
     with torch.no_grad():                                                 # reference: forward with graph, then .detach()
         fake_images = generator(z, features, masks)
 
