@@ -128,16 +128,19 @@ def main():
         it[0] += 1
         train_type = random.choices([1, 2], [0.6, 0.4])
         images = pool[it[0] % len(pool)]
-        images_d = normalizer_d(images)
-        with torch.no_grad():
-            _, features = C(normalizer_clf(images))
-        L = random.randint(1, len(features) - 2)
-        masks = [f.clone() for f in features]
-        if train_type == 1:
-            tm.setMasksPart1(masks, device, L)
-        else:
-            tm.setMasksPart2(masks, device, L)
-        tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks)
+        with tm.prefetch(G, device) as pf:       # independent of the previous critic step: overlaps its backward
+            images_d = normalizer_d(images)
+            with torch.no_grad():
+                _, features = C(normalizer_clf(images))
+            L = random.randint(1, len(features) - 2)
+            masks = [f.clone() for f in features]
+            if train_type == 1:
+                tm.setMasksPart1(masks, device, L)
+            else:
+                tm.setMasksPart2(masks, device, L)
+            fake = tm.fake_for_discriminator(G, B, features, masks)
+            pf.hand_over(images_d, features, masks, fake)
+        tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks, fake_images=fake)
         if it[0] % 5 == 1:
             tm.train_generator(G, D, g_loss_fn, g_opt, B, features, crit, L, C, normalizer_clf, crit, crit, masks, train_type)
 
@@ -170,8 +173,8 @@ def main():
     elapsed_instr = None
     if timing:
         # single-stream for this pass: a kernel's event-to-event time is only its own duration when nothing else shares the GPU
-        saved = (ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV)
-        ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = False
+        saved = (ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH)
+        ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = ops.PREFETCH = False
         _lib.check(_lib.lib.sempyr_profile_begin(4096 * max(a.steps, 1)), "sempyr_profile_begin")
         t1 = time.perf_counter()
         for _ in range(a.steps):
@@ -179,7 +182,7 @@ def main():
         barrier()
         elapsed_instr = time.perf_counter() - t1
         _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
-        ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV = saved
+        ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH = saved
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -105,6 +105,7 @@ class async_param_grads:
 
 TWO_STREAM_CRITIC = os.environ.get("SEMPYR_TWO_STREAM", "1") != "0"
 TWO_STREAM_GENERATOR = os.environ.get("SEMPYR_TWO_STREAM_G", "1") != "0"
+PREFETCH = os.environ.get("SEMPYR_PREFETCH", "1") != "0"
 
 
 def side_stream(device):
@@ -121,6 +122,23 @@ def _side_stream2(device):
         s = torch.cuda.Stream(device=device)
         _SIDE2[device.index] = s
     return s
+
+
+_PRE = {}
+
+
+def prefetch_stream(device):
+    """Third stream: work of the NEXT critic step that does not depend on the current one (see train_model.prefetch)."""
+    s = _PRE.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _PRE[device.index] = s
+    return s
+
+
+def consumer_streams(device):
+    """Every stream of this library on `device` that may read a tensor handed over from the prefetch stream."""
+    return [torch.cuda.current_stream(device), _side_stream(device), _side_stream2(device)]
 
 
 def _is_leaf_param(t):

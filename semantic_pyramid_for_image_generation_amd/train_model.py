@@ -199,7 +199,68 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
             total_loss.backward()
     parallel.sync_gradients(generator)
     generator_optimizer.step()
+    if device.type == 'cuda':
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        _GEN_UPDATED[id(generator)] = ev
     return loses_dictionary
+
+
+_GEN_UPDATED = {}        # id(generator) -> event recorded behind its last optimizer step
+
+
+class prefetch:
+    """`with prefetch(generator, device) as pf:` — run the part of a loop iteration that does not depend on the previous
+    critic step (classifier taps, masks, and the detached generator forward of train_discriminator, reference
+    train_model.py:308-318,125-126) on a separate stream.  That stream waits only for the generator's last update, so the
+    work overlaps the previous iteration's critic backward, which the host has already queued.  Tensors created inside are
+    handed to the other streams by `pf.hand_over(...)`; `train_discriminator(..., fake_images=...)` then waits for the block.
+    Outside CUDA (or with SEMPYR_PREFETCH=0) the block runs in place."""
+
+    def __init__(self, generator, device):
+        self.on = ops.PREFETCH and device.type == 'cuda'
+        self.generator, self.device = generator, device
+        self.done = None
+
+    def __enter__(self):
+        if self.on:
+            self.main = torch.cuda.current_stream(self.device)
+            self.stream = ops.prefetch_stream(self.device)
+            ev = _GEN_UPDATED.get(id(self.generator))
+            if ev is not None:
+                self.stream.wait_event(ev)
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+        return self
+
+    def hand_over(self, *tensors):
+        """Mark tensors created in the block as used by the library's other streams (caching-allocator bookkeeping)."""
+        if self.on:
+            for t in tensors:
+                for item in (t if isinstance(t, (list, tuple)) else [t]):
+                    for st in self.consumers:
+                        item.record_stream(st)
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.done = torch.cuda.Event()
+            self.done.record(self.stream)
+            self.ctx.__exit__(*exc)
+            self.main.wait_event(self.done)
+
+    @property
+    def consumers(self):
+        return [self.main] + ops.consumer_streams(self.device)[1:]
+
+
+def fake_for_discriminator(generator, batch_size, features, masks, z=None):
+    """The detached generator forward of a critic step (reference train_model.py:125-126): z from the CPU generator."""
+    device = features[1].device
+    generator.train()
+    if z is None:
+        z = _cpu_randn_to(device, batch_size, 128, 1, 1)
+    with torch.no_grad():
+        return generator(z, features, masks)
 
 
 _PINNED = {}
@@ -233,15 +294,14 @@ def _samplewise(module):
 
 
 def train_discriminator(generator, discriminator, discriminator_loss_fn, discriminator_optimizer, real_images, features, masks,
-                        z=None, alpha=None):
-    """One critic step (reference :122-145): real/fake logits + 10 * gradient penalty (double backward)."""
+                        z=None, alpha=None, fake_images=None):
+    """One critic step (reference :122-145): real/fake logits + 10 * gradient penalty (double backward).
+    `fake_images` may carry the result of fake_for_discriminator() computed ahead of time (see `prefetch`)."""
     device = real_images.device
     generator.train()
     discriminator.train()
-    if z is None:
-        z = _cpu_randn_to(device, real_images.shape[0], 128, 1, 1)        # CPU generator, as in the reference (Q7)
-    with torch.no_grad():                                                 # reference: forward with graph, then .detach()
-        fake_images = generator(z, features, masks)
+    if fake_images is None:                                               # reference: forward with graph, then .detach()
+        fake_images = fake_for_discriminator(generator, real_images.shape[0], features, masks, z)   # CPU-generator z (Q7)
 
     def logits_loss():
         if _samplewise(discriminator):
@@ -419,6 +479,10 @@ def _main():
                 print('epoch:', epoch, ', iter', iterations, 'start, time =', time.time() - starting_time, 'seconds')
                 starting_time = time.time()
             images, _ = data
+            # everything up to the critic's own forward is independent of the previous critic step: it runs on the
+            # prefetch stream and overlaps that step's backward (see `prefetch`)
+            pf = prefetch(generator, device)
+            pf.__enter__()
             images = images.to(device, non_blocking=True)
             images_discriminator = normalizer_discriminator(images)
             images_clf = normalizer_clf(images)
@@ -445,8 +509,12 @@ def _main():
                 setMasksPart1(masks, device, features_to_train)
             else:
                 setMasksPart2(masks, device, features_to_train)
+            fake_images = fake_for_discriminator(generator, images.shape[0], features, masks)
+            pf.hand_over(images, images_discriminator, features, masks, fake_images)
+            pf.__exit__(None, None, None)
             discriminator_loss_dict = train_discriminator(generator, discriminator, criterion_discriminator,
-                                                          discriminator_optimizer, images_discriminator, features, masks)
+                                                          discriminator_optimizer, images_discriminator, features, masks,
+                                                          fake_images=fake_images)
             for k, v in discriminator_loss_dict.items():
                 pending.append(('D/%s' % k, iterations, v.detach()))
                 if iterations % 30 == 1:

@@ -252,3 +252,59 @@ def test_stream_overlap_matches_single_stream(dev):
     for k in l0:
         assert l1[k] == l2[k]
         assert abs(l1[k] - l0[k]) <= 1e-6 * max(1.0, abs(l0[k])), k
+
+
+def test_prefetched_iterations_match_in_place(dev):
+    """Three loop iterations (critic steps, one generator step) with the classifier / mask / detached-generator part on
+    the prefetch stream, against the same iterations executed in place: identical parameters afterwards (same kernels in
+    the same per-stream order, so bit-identical) and identical losses."""
+    from semantic_pyramid_for_image_generation_amd import ops
+    tm, G, D, C, tr, images, feats, masks0, z, z2, alpha = _setup(dev, 'res', 'instance_norm', False, 81, B=4)
+    d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
+    crit = tm.L1Loss()
+    gstate = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    dstate = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    norm_clf = tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD)
+    norm_d = tm.Normalize([0.5] * 3, [0.5] * 3)
+    imgs = images.to(dev)
+
+    def run(prefetch_on):
+        saved = ops.PREFETCH
+        ops.PREFETCH = prefetch_on
+        try:
+            G.load_state_dict(gstate); D.load_state_dict(dstate)
+            d_opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            g_opt = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            torch.manual_seed(5); rnd = random.Random(5)
+            losses = []
+            for it in range(1, 4):
+                with tm.prefetch(G, dev) as pf:
+                    images_d = norm_d(imgs)
+                    with torch.no_grad():
+                        _, features = C(norm_clf(imgs))
+                    L = rnd.randint(1, len(features) - 2)
+                    masks = [f.clone() for f in features]
+                    state = random.getstate(); random.seed(100 + it)
+                    tm.setMasksPart2(masks, dev, L)
+                    random.setstate(state)
+                    fake = tm.fake_for_discriminator(G, imgs.shape[0], features, masks)
+                    pf.hand_over(images_d, features, masks, fake)
+                out = tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks, fake_images=fake,
+                                             alpha=alpha[:imgs.shape[0]].to(dev))
+                losses += [out['d_loss'].detach().clone(), out['gp'].detach().clone()]
+                if it == 1:
+                    og = tm.train_generator(G, D, g_loss_fn, g_opt, imgs.shape[0], features, crit, L, C, norm_clf, crit, crit,
+                                            masks, [2])
+                    losses.append(og['total_loss'].detach().clone())
+            torch.cuda.synchronize()
+            return ([float(v) for v in losses], {k: v.detach().clone() for k, v in D.state_dict().items()},
+                    {k: v.detach().clone() for k, v in G.state_dict().items()})
+        finally:
+            ops.PREFETCH = saved
+    l1, d1, g1 = run(True)
+    l0, d0, g0 = run(False)
+    assert l1 == l0
+    for k in d0:
+        assert torch.equal(d1[k], d0[k]), k
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
