@@ -9,7 +9,7 @@ import torch.optim as optim
 
 from . import ops, parallel
 from .featuresCreatorGen import Features1ToImage, FeaturesDiscriminator, LevelUpFeaturesGenerator
-from .train_model import (L1Loss, Normalize, _frozen, get_wgan_losses_fn, gradient_penalty, load_classifier,
+from .train_model import (L1Loss, Normalize, _ensure_train, _frozen, get_wgan_losses_fn, gradient_penalty, load_classifier,
                           print_gpu_details)
 
 args = None
@@ -18,8 +18,8 @@ args = None
 def train_generator(features_gen, discriminator, classifier, features_gen_optimizer, features, features_to_train,
                     generator_loss_fn, criterion_features, next_level_features_criterion):
     """adversarial + classifier-stage reconstruction + 0.2 * next-level L1 (reference :30-58)."""
-    features_gen.train()
-    discriminator.train()
+    _ensure_train(features_gen)
+    _ensure_train(discriminator)
     with _frozen(discriminator, classifier):
         created = features_gen(features[features_to_train])
         generator_loss = generator_loss_fn(discriminator(created))
@@ -45,8 +45,8 @@ def train_generator(features_gen, discriminator, classifier, features_gen_optimi
 def train_discriminator(features_gen, discriminator, discriminator_loss_fn, discriminator_optimizer, features, features_to_train,
                         alpha=None):
     """critic step on feature tensors with the gradient penalty (reference :61-79)."""
-    features_gen.train()
-    discriminator.train()
+    _ensure_train(features_gen)
+    _ensure_train(discriminator)
     with torch.no_grad():
         fake_features = features_gen(features[features_to_train])
     real = features[features_to_train - 1]
