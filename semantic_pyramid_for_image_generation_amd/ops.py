@@ -39,6 +39,28 @@ def _stream():
     return _raw_stream(_cur_device())
 
 
+class _NoCtx:
+    """Stand-in for the autograd context when nothing is recorded."""
+    needs_input_grad = (False,) * 16
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def _apply(fn, *args):
+    """fn.apply(*args); with autograd off (no_grad forwards, and every operator call made from inside a plain backward
+    pass) the Function's forward runs directly — no graph bookkeeping, ~10 us less host time per call."""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NoCtx(), *args)
+
+
 def _req(t, name="tensor"):
     if not t.is_cuda:
         raise _lib.SempyrError(f"{name}: the sempyr operators run on the GPU only (got a {t.device} tensor); "
@@ -360,9 +382,9 @@ class _ConvFwd(Function):
         plan = ctx.plan
         gy = gy.contiguous()
         if ctx.pool:
-            gy = _Pool2Up.apply(gy, 0.25, y, *ctx.act)
+            gy = _apply(_Pool2Up, gy, 0.25, y, *ctx.act)
         elif y is not None:
-            gy = _ActBwd.apply(gy, y, *ctx.act)
+            gy = _apply(_ActBwd, gy, y, *ctx.act)
         gx = gw = gb = None
         if not _INPUT_GRADS_ONLY:
             want_w = ctx.needs_input_grad[1]
@@ -371,7 +393,7 @@ class _ConvFwd(Function):
                 _param_grads_async(gy, x, plan, w, bias, want_w, want_b)     # issued first: overlaps the input gradient
             else:
                 if want_w:
-                    gw = _ConvWgrad.apply(gy, x, plan)
+                    gw = _apply(_ConvWgrad, gy, x, plan)
                 if want_b:
                     gb = _bias_grad(gy)
         if ctx.needs_input_grad[0]:
@@ -380,9 +402,9 @@ class _ConvFwd(Function):
 
 
 def _conv_input_grad(gy, w, plan):
-    gx = _ConvDgrad.apply(gy, w, None, plan.noups())
+    gx = _apply(_ConvDgrad, gy, w, None, plan.noups())
     if plan.ups:
-        gx = _Pool2Down.apply(gx, 1.0)
+        gx = _apply(_Pool2Down, gx, 1.0)
     return gx
 
 
@@ -413,11 +435,11 @@ class _ConvDgrad(Function):
                 _param_grads_async(gy, u, plan, w, None, want_w, False)
             else:
                 if want_w:
-                    g_w = _ConvWgrad.apply(gy, u, plan)
+                    g_w = _apply(_ConvWgrad, gy, u, plan)
                 if want_b:
                     g_b = _bias_grad(u)
         if ctx.needs_input_grad[0]:
-            g_gy = _ConvFwd.apply(u, w, None, plan)
+            g_gy = _apply(_ConvFwd, u, w, None, plan)
         return g_gy, g_w, g_b, None
 
 
@@ -438,7 +460,7 @@ class _ConvWgrad(Function):
         ggw = ggw.contiguous()
         g_gy = g_x = None
         if ctx.needs_input_grad[0]:
-            g_gy = _ConvFwd.apply(x, ggw, None, plan)
+            g_gy = _apply(_ConvFwd, x, ggw, None, plan)
         if ctx.needs_input_grad[1]:
             g_x = _conv_input_grad(gy, ggw, plan)
         return g_gy, g_x, None
@@ -456,7 +478,7 @@ def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NO
     plan = get_plan((B, Cin, H, W, Cout, kh, kw, stride, padding, 1 if upsample else 0), x.device)
     if pool and (plan.Ho % 2 or plan.Wo % 2):
         raise _lib.SempyrError("conv2d: pooled output needs even output height and width")
-    return _ConvFwd.apply(x, w, bias, plan, act_kind, slope, pool)
+    return _apply(_ConvFwd, x, w, bias, plan, act_kind, slope, pool)
 
 
 def conv_transpose2d(x, w, bias=None, stride=1, padding=0):
@@ -471,7 +493,7 @@ def conv_transpose2d(x, w, bias=None, stride=1, padding=0):
     plan = get_plan((B, Cout_t, Ho, Wo, Cin_t, kh, kw, stride, padding, 0), x.device)
     if plan.Ho != H or plan.Wo != W:
         raise _lib.SempyrError("conv_transpose2d: inconsistent geometry")
-    return _ConvDgrad.apply(x, w, bias, plan)
+    return _apply(_ConvDgrad, x, w, bias, plan)
 
 
 def linear(x, w, bias=None):
@@ -526,7 +548,7 @@ class _NormAct(Function):
     def backward(ctx, gy):
         x, y, gamma, rowbuf = ctx.saved_tensors
         kind, act_kind, slope = ctx.cfg
-        gx, gg, gb = _NormActBwd.apply(gy.contiguous(), x, y, gamma, rowbuf, kind, act_kind, slope)
+        gx, gg, gb = _apply(_NormActBwd, gy.contiguous(), x, y, gamma, rowbuf, kind, act_kind, slope)
         if _INPUT_GRADS_ONLY:
             gg = gb = None
         return gx, gg, gb, None, None, None, None, None
@@ -561,9 +583,9 @@ class _NormAddNormAct(Function):
         kind, act_kind, slope = ctx.cfg
         g = gy.contiguous()
         if y is not None:
-            g = _ActBwd.apply(g, y, act_kind, slope)
-        ga, gga, gba = _NormActBwd.apply(g, a, None, gamma_a, ra, kind, ACT_NONE, 0.0)
-        gb, ggb, gbb = _NormActBwd.apply(g, b, None, gamma_b, rb, kind, ACT_NONE, 0.0)
+            g = _apply(_ActBwd, g, y, act_kind, slope)
+        ga, gga, gba = _apply(_NormActBwd, g, a, None, gamma_a, ra, kind, ACT_NONE, 0.0)
+        gb, ggb, gbb = _apply(_NormActBwd, g, b, None, gamma_b, rb, kind, ACT_NONE, 0.0)
         if _INPUT_GRADS_ONLY:
             gga = gba = ggb = gbb = None
         return ga, gga, gba, None, gb, ggb, gbb, None, None, None, None, None, None
@@ -622,13 +644,13 @@ def norm_act(x, gamma, beta, kind, act_kind=ACT_NONE, slope=0.0, eps=1e-5, bn_st
     """Training-mode BatchNorm2d / InstanceNorm2d(affine) / GroupNorm(1,C) fused with ReLU or
     LeakyReLU (reference generator.py:27-29, discriminator.py:37-39).  `bn_state` =
     (running_mean, running_var, num_batches_tracked, momentum) is updated in place for BATCH."""
-    return _NormAct.apply(x, gamma, beta, kind, act_kind, slope, eps, bn_state)
+    return _apply(_NormAct, x, gamma, beta, kind, act_kind, slope, eps, bn_state)
 
 
 def norm_add_norm_act(a, gamma_a, beta_a, b, gamma_b, beta_b, kind, act_kind=ACT_NONE, slope=0.0, eps_a=1e-5, eps_b=1e-5,
                       state_a=None, state_b=None):
     """act(norm(a) + norm(b)) for two training-mode norm layers of the same kind (generator.py:54-57)."""
-    return _NormAddNormAct.apply(a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b)
+    return _apply(_NormAddNormAct, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b)
 
 
 class _AffineRowAct(Function):
@@ -691,7 +713,7 @@ def bn_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, res=None, a
             gamma._sempyr_bn_eval = (key, coeffs)
         except Exception:  # pragma: no cover
             pass
-    return _AffineRowAct.apply(x, res, coeffs, act_kind, slope)
+    return _apply(_AffineRowAct, x, res, coeffs, act_kind, slope)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -723,7 +745,7 @@ class _AddAct(Function):
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         act_kind, slope, has_b = ctx.cfg
-        g = gy if act_kind == ACT_NONE else _ActBwd.apply(gy, y, act_kind, slope)
+        g = gy if act_kind == ACT_NONE else _apply(_ActBwd, gy, y, act_kind, slope)
         return g, (g if has_b else None), None, None
 
 
@@ -746,18 +768,18 @@ class _ActBwd(Function):
         act_kind, slope = ctx.cfg
         if act_kind == ACT_TANH:
             raise NotImplementedError("double backward through tanh is not part of the hot path")
-        return _ActBwd.apply(u.contiguous(), y, act_kind, slope), None, None, None
+        return _apply(_ActBwd, u.contiguous(), y, act_kind, slope), None, None, None
 
 
 def act(x, act_kind, slope=0.0):
     """nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh (generator.py:48,120 ; discriminator.py:99,102)."""
-    return _AddAct.apply(x, None, act_kind, slope)
+    return _apply(_AddAct, x, None, act_kind, slope)
 
 
 def add_act(a, b, act_kind=ACT_NONE, slope=0.0):
     """`x += residual; x = activation(x)` (generator.py:56-57, discriminator.py:63-64) and gen + features
     (generator.py:87)."""
-    return _AddAct.apply(a, b, act_kind, slope)
+    return _apply(_AddAct, a, b, act_kind, slope)
 
 
 class _Mul(Function):
@@ -774,14 +796,14 @@ class _Mul(Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        ga = _Mul.apply(g.contiguous(), b) if ctx.needs_input_grad[0] else None
-        gb = _Mul.apply(g.contiguous(), a) if ctx.needs_input_grad[1] else None
+        ga = _apply(_Mul, g.contiguous(), b) if ctx.needs_input_grad[0] else None
+        gb = _apply(_Mul, g.contiguous(), a) if ctx.needs_input_grad[1] else None
         return ga, gb
 
 
 def mul(a, b):
     """features[i] * masks[i] (generator.py:126-129)."""
-    return _Mul.apply(a, b)
+    return _apply(_Mul, a, b)
 
 
 class _Normalize(Function):
@@ -798,12 +820,12 @@ class _Normalize(Function):
     @staticmethod
     def backward(ctx, g):
         mean_c, std_c = ctx.saved_tensors
-        return _Normalize.apply(g.contiguous(), mean_c, std_c, True), None, None, None
+        return _apply(_Normalize, g.contiguous(), mean_c, std_c, True), None, None, None
 
 
 def normalize(x, mean_c, std_c):
     """transforms.Normalize(mean, std) on a batch (train_model.py:240-245,308-309,98)."""
-    return _Normalize.apply(x, mean_c, std_c, False)
+    return _apply(_Normalize, x, mean_c, std_c, False)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -827,7 +849,7 @@ class _Pool2Down(Function):
     def backward(ctx, g):
         (yref,) = ctx.saved_tensors
         scale, act_kind, slope = ctx.cfg
-        return _Pool2Up.apply(g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
+        return _apply(_Pool2Up, g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
 
 
 class _Pool2Up(Function):
@@ -848,17 +870,17 @@ class _Pool2Up(Function):
     def backward(ctx, g):
         (yref,) = ctx.saved_tensors
         scale, act_kind, slope = ctx.cfg
-        return _Pool2Down.apply(g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
+        return _apply(_Pool2Down, g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
 
 
 def avg_pool2(x):
     """nn.AvgPool2d(2) (discriminator.py:57,103)."""
-    return _Pool2Down.apply(x, 0.25)
+    return _apply(_Pool2Down, x, 0.25)
 
 
 def upsample2(x):
     """nn.UpsamplingNearest2d(scale_factor=2) as a standalone op (normally fused into conv2d)."""
-    return _Pool2Up.apply(x, 1.0)
+    return _apply(_Pool2Up, x, 1.0)
 
 
 class _MaxPool3s2(Function):
@@ -890,7 +912,7 @@ class _MaxPool3s2(Function):
 
 def max_pool3s2(x):
     """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet18 stem (classifier.py:36)."""
-    return _MaxPool3s2.apply(x)
+    return _apply(_MaxPool3s2, x)
 
 
 def global_avg_pool(x):
@@ -937,7 +959,7 @@ class _Mean(Function):
 
 def mean(x, scale=1.0):
     """`x.mean()` / `-x.mean()` of the WGAN losses (train_model.py:39-46)."""
-    return _Mean.apply(x, scale)
+    return _apply(_Mean, x, scale)
 
 
 class _L1Mean(Function):
@@ -975,7 +997,7 @@ class _L1Mean(Function):
 def l1_mean(a, b, mask=None):
     """nn.L1Loss()(a*mask, b*mask) in one pass (train_model.py:217-221) ; mask=None: nn.L1Loss()(a, b)
     (train_model.py:109 ; train_feature_creation_gen.py:47,50)."""
-    return _L1Mean.apply(a, b, mask)
+    return _apply(_L1Mean, a, b, mask)
 
 
 class _GPLoss(Function):
@@ -1007,7 +1029,7 @@ class _GPLoss(Function):
 
 def gp_loss(grad):
     """one_mean_gp(grad) (train_model.py:63-66)."""
-    return _GPLoss.apply(grad)
+    return _apply(_GPLoss, grad)
 
 
 def lerp_rows(real, fake, alpha):
