@@ -182,17 +182,33 @@ def _accumulate_grad(param, g, main):
         param.grad.add_(g)
 
 
+_STREAM_OBJ = {}
+
+
+def _current_stream_obj(device):
+    """torch.cuda.current_stream(device) through a raw-handle cache (the torch call costs ~20 us, see _stream)."""
+    raw = _raw_stream(device.index)
+    st = _STREAM_OBJ.get((device.index, raw))
+    if st is None:
+        st = torch.cuda.current_stream(device)
+        _STREAM_OBJ[(device.index, raw)] = st
+    return st
+
+
 def _param_grads_async(gy, x, plan, w, bias, want_w, want_b):
     """WGRAD(gy, x) -> w.grad and channel_sum(gy) -> bias.grad on the side stream."""
     dev = gy.device
-    main = torch.cuda.current_stream(dev)
+    main = _current_stream_obj(dev)
     side = _side_stream(dev)
     side.wait_stream(main)
-    with torch.cuda.stream(side):
+    torch.cuda.set_stream(side)            # (the `with torch.cuda.stream(...)` context costs ~40 us of host time)
+    try:
         if want_w:
             _accumulate_grad(w, _raw_conv_wgrad(plan, gy, x), main)
         if want_b:
             _accumulate_grad(bias, _channel_sum_raw(gy), main)
+    finally:
+        torch.cuda.set_stream(main)
     gy.record_stream(side)
     x.record_stream(side)
     _SIDE_DIRTY.add(dev.index)
