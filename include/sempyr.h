@@ -82,12 +82,16 @@ int sempyr_conv2d_tables(const sempyr_conv_desc* d, int mode, int32_t* ktab_host
 int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, const float* w,
                                const int32_t* wsrc_dev, float* wpacked, void* stream);
 
-/* y[B,Cout,Ho,Wo] = act(conv(x, w) (+ bias[Cout] if bias != NULL)); act is a SEMPYR_ACT_* code applied in the
+/* y[B,Cout,Ho,Wo] = act(scale[Cout] * conv(x, w) + bias[Cout] + res[B,Cout,Ho,Wo]); scale, bias and res are each optional
+ * (NULL = absent). scale + bias fold an eval-mode BatchNorm2d into the epilogue and res the identity branch of a ResNet
+ * BasicBlock (the frozen classifier, classifier.py:34-40 under .eval(); the generator under eval_model.py). They are
+ * rejected for Cout <= 4 and together with y_pooled. act is a SEMPYR_ACT_* code applied in the
  * kernel epilogue (`conv -> LeakyReLU` of the critic stem discriminator.py:106-107, `conv -> Tanh` of the generator head
  * generator.py:116-120), slope the LeakyReLU slope. y_pooled (optional, [B,Cout,Ho/2,Wo/2]) also receives
  * AvgPool2d(2)(y) (discriminator.py:109), computed in the same epilogue when the launch is a single pass. */
 int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wpacked_fwd,
-                      const int32_t* ktab_fwd_dev, const float* bias, int act, float slope, float* y,
+                      const int32_t* ktab_fwd_dev, const float* bias, const float* scale, const float* res,
+                      int act, float slope, float* y,
                       float* y_pooled, void* workspace, size_t workspace_bytes, void* stream);
 
 /* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a

@@ -74,6 +74,18 @@ def run_norm(layer, x, act_kind=ops.ACT_NONE, slope=0.0, res=None):
     return ops.add_act(y, res, act_kind, slope) if res is not None else y
 
 
+def run_conv_norm(conv, norm, x, act_kind=ops.ACT_NONE, slope=0.0, res=None, upsample=False):
+    """act(norm(conv(x)) [+ res]).  A bias-free Conv2d followed by an eval-mode BatchNorm2d (every conv of the frozen
+    ResNet18 classifier; the generator under .eval()) is one launch: scale / shift, residual and activation run in the
+    convolution's epilogue.  Everything else is run_conv followed by run_norm."""
+    if (isinstance(conv, nn.Conv2d) and conv.bias is None and conv.out_channels > 4 and isinstance(norm, nn.BatchNorm2d)
+            and not norm.training and norm.track_running_stats and norm.affine):
+        return ops.conv_bn_eval_act(x, conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps,
+                                    _single(conv.stride), _single(conv.padding), upsample=upsample, res=res,
+                                    act_kind=act_kind, slope=slope)
+    return run_norm(norm, run_conv(conv, x, upsample=upsample), act_kind, slope, res=res)
+
+
 def _train_norm_kind(layer):
     """(kind, bn_state) when `layer` is a norm container that computes batch statistics right now, else None."""
     if isinstance(layer, nn.BatchNorm2d):
@@ -120,4 +132,4 @@ def run_conv_norm_act(block, x, upsample=False):
     (generator.py:27-29, discriminator.py:37-39)."""
     conv, norm, act = block[0], block[1], block[2]
     kind, slope = activation_kind(act)
-    return run_norm(norm, run_conv(conv, x, upsample=upsample), kind, slope)
+    return run_conv_norm(conv, norm, x, kind, slope, upsample=upsample)

@@ -7,7 +7,7 @@ pass.  `classifier.layer2/3/4(x)` can be called directly, as `train_feature_crea
 import torch.nn as nn
 
 from . import ops
-from .blocks import run_conv, run_norm
+from .blocks import run_conv_norm
 from .resnet import HipStage, resnet18  # noqa: F401  (resnet18 re-exported for model construction)
 
 
@@ -37,8 +37,7 @@ class Classifier(nn.Module):
             raise NotImplementedError(f"stem max-pool {geom} has no HIP kernel (ResNet uses 3/2/1)")
 
     def forward(self, inputs):
-        conv1 = run_conv(self.conv1, inputs)
-        relu = run_norm(self.bn1, conv1, ops.ACT_RELU)
+        relu = run_conv_norm(self.conv1, self.bn1, inputs, ops.ACT_RELU)
         maxpool = ops.max_pool3s2(relu)
         layer1 = self.layer1(maxpool)
         layer2 = self.layer2(layer1)

@@ -78,6 +78,8 @@ struct IgemmParams {
     const float* A;        // GATHER: packed weights [Kpad][Mpad]; WGRAD: gy [B][M][QH*QW]
     const float* X;        // gathered tensor
     float* Out;            // output tensor, or slab base when splits > 1 / WGRAD
+    const float* scale;    // per-m scale applied before the bias (eval-mode BatchNorm folded into the epilogue), or null
+    const float* res;      // residual in the output's layout, added before the activation, or null
     const float* bias;     // per-m bias (only applied when splits == 1, GATHER mode)
     const int2* ktab;      // gather table: GATHER -> indexed by k ; WGRAD -> indexed by n
     int M, Mpad, N, K, Kpad;
@@ -398,6 +400,21 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
     const int l31 = lane & 31, kh = lane >> 5;
     const bool full_m = (m0 + BM) <= p.M;                        // workgroup-uniform: no per-row guard needed
     if constexpr (MODE == MODE_GATHER) {
+        if (p.scale) {                                           // uniform: y = act(scale[m] * conv + bias[m] + res)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float sv[16];
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                    sv[r16] = p.scale[m < p.M ? m : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] *= sv[r16];
+            }
+        }
         if (p.bias) {                                            // uniform; all bias loads issued before any use
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -411,6 +428,25 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] += bv[r16];
+            }
+        }
+        if (p.res) {                                             // uniform
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (n >= pN) continue;
+                int b, qy, qx;
+                decode_pixel(n, pQHW, pQW, p.quad, b, qy, qx);
+                const float* rp = p.res + (size_t)b * p.OCHW + (qy * p.OSY + pOPY) * p.OW + qx * p.OSX + pOPX;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) {
+                        const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                        acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * p.OHW];
+                    }
+                }
             }
         }
         if (p.act != SEMPYR_ACT_NONE) {                          // uniform
@@ -662,6 +698,21 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
     // epilogue (as the generic kernel's GATHER epilogue)
     float* out = p.Out + (size_t)split * p.slab_stride;
     const bool full_m = (m0 + BM) <= p.M;
+    if (p.scale) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float sv[16];
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                sv[r16] = p.scale[m < p.M ? m : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] *= sv[r16];
+        }
+    }
     if (p.bias) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -675,6 +726,22 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] += bv[r16];
+        }
+    }
+    if (p.res) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+            const float* rp = p.res + (size_t)tb * p.OCHW + (n - tb * p.QHW);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                    acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * p.OHW];
+                }
+            }
         }
     }
     if (p.act != SEMPYR_ACT_NONE) {
@@ -888,7 +955,8 @@ __global__ __launch_bounds__(256) void rgb3x3_kernel(const IgemmParams p)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                             const float* __restrict__ bias, int splits,
                                                             long long slab_stride, int total4, int OHW, int OC,
-                                                            int act, float slope)
+                                                            int act, float slope, const float* __restrict__ scale,
+                                                            const float* __restrict__ res)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
@@ -898,11 +966,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const float4 v = *(reinterpret_cast<const float4*>(slabs + (size_t)k * slab_stride) + i);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    if (scale) {
+        const int e = i * 4;
+        a.x *= scale[(e / OHW) % OC]; a.y *= scale[((e + 1) / OHW) % OC];
+        a.z *= scale[((e + 2) / OHW) % OC]; a.w *= scale[((e + 3) / OHW) % OC];
+    }
     if (bias) {
         const int e = i * 4;
         // OHW may be < 4 (1x1 outputs): resolve the channel per element
         a.x += bias[(e / OHW) % OC]; a.y += bias[((e + 1) / OHW) % OC];
         a.z += bias[((e + 2) / OHW) % OC]; a.w += bias[((e + 3) / OHW) % OC];
+    }
+    if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
     }
     if (act != SEMPYR_ACT_NONE) {
         a.x = act_apply(a.x, act, slope); a.y = act_apply(a.y, act, slope);
@@ -914,13 +991,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void splitk_reduce_tail_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                  const float* __restrict__ bias, int splits,
                                                                  long long slab_stride, int begin, int total, int OHW, int OC,
-                                                                 int act, float slope)
+                                                                 int act, float slope, const float* __restrict__ scale,
+                                                                 const float* __restrict__ res)
 {
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     float a = slabs[i];
     for (int k = 1; k < splits; ++k) a += slabs[(size_t)k * slab_stride + i];
+    if (scale) a *= scale[(i / OHW) % OC];
     if (bias) a += bias[(i / OHW) % OC];
+    if (res) a += res[i];
     out[i] = act_apply(a, act, slope);
 }
 
@@ -1422,23 +1502,25 @@ extern "C" int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, c
 }
 
 static int run_splitk_reduce(const float* slabs, float* out, const float* bias, int splits, long long numel,
-                             int OHW, int OC, int act, float slope, hipStream_t st)
+                             int OHW, int OC, int act, float slope, hipStream_t st,
+                             const float* scale = nullptr, const float* res = nullptr)
 {
     // float4 path only when every slab start (k * numel floats) stays 16-byte aligned
-    if (numel % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0) {
+    if (numel % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)res) & 15) == 0) {
         const int total4 = (int)(numel / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st,
-                           slabs, out, bias, splits, numel, total4, OHW, OC, act, slope);
+                           slabs, out, bias, splits, numel, total4, OHW, OC, act, slope, scale, res);
     } else {
         hipLaunchKernelGGL(splitk_reduce_tail_kernel, dim3(ceil_div(numel, 256)), dim3(256), 0, st,
-                           slabs, out, bias, splits, numel, 0, (int)numel, OHW, OC, act, slope);
+                           slabs, out, bias, splits, numel, 0, (int)numel, OHW, OC, act, slope, scale, res);
     }
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
-                                 const int32_t* ktab, const float* bias, int act, float slope, float* y,
+                                 const int32_t* ktab, const float* bias, const float* scale, const float* res,
+                                 int act, float slope, float* y,
                                  float* y_pooled, void* ws, size_t ws_bytes, void* stream)
 {
     sempyr_conv_plan pl;
@@ -1463,7 +1545,9 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     p.chunks_per_split = ceil_div(p.nchunks, splits);
     p.C = d->Cin;
     p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = (int)(pl.wpack_floats * 4);
-    if (splits == 1) { p.Out = y; p.bias = bias; p.slab_stride = 0; p.act = act; p.slope = slope; }
+    if ((scale || res) && (d->Cout <= 4 || y_pooled))
+        SEMPYR_FAIL("conv fwd: the scale / residual epilogue is not available for RGB heads or pooled outputs");
+    if (splits == 1) { p.Out = y; p.bias = bias; p.scale = scale; p.res = res; p.slab_stride = 0; p.act = act; p.slope = slope; }
     else { p.Out = (float*)ws; p.bias = nullptr; p.slab_stride = out_numel; }
     if (y_pooled && ((pl.Ho | pl.Wo) & 1)) SEMPYR_FAIL("conv fwd: pooled output needs even output height and width");
     if (y_pooled && act == SEMPYR_ACT_TANH) SEMPYR_FAIL("conv fwd: pooled output is defined for ReLU-family activations");
@@ -1478,7 +1562,7 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     }
     if (rc) return rc;
     if (splits > 1)
-        if ((rc = run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st))) return rc;
+        if ((rc = run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st, scale, res))) return rc;
     if (y_pooled && !fused_pool)
         return sempyr_pool2_down(y, nullptr, y_pooled, d->B * d->Cout, pl.Ho, pl.Wo, 0.25f, SEMPYR_ACT_NONE, 0.f, stream);
     return 0;

@@ -5,7 +5,8 @@ convolutions instead of being materialised (reference generator.py:51-52,85)."""
 import torch.nn as nn
 
 from . import ops
-from .blocks import init_weights, run_conv, run_conv_norm_act, run_norm_add_norm_act  # noqa: F401  (init_weights re-exported)
+from .blocks import (init_weights, run_conv, run_conv_norm, run_conv_norm_act,  # noqa: F401  (init_weights re-exported)
+                     run_norm_add_norm_act)
 
 
 class ConvBlock(nn.Module):
@@ -40,6 +41,11 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         up = self.need_upsample           # both consumers gather through the x2 upsample; no 4x tensor is written
+        if not (self.conv_block2.block[1].training or self.skip_block.block[1].training):
+            # eval mode (eval_model.py / `sample`): each BatchNorm folds into its conv, the add + ReLU into the last one
+            residual = run_conv_norm(self.skip_block.block[0], self.skip_block.block[1], x, upsample=up)
+            h = self.conv_block1(x, upsample=up)
+            return run_conv_norm(self.conv_block2.block[0], self.conv_block2.block[1], h, ops.ACT_RELU, res=residual)
         residual = run_conv(self.skip_block.block[0], x, upsample=up)
         h = self.conv_block1(x, upsample=up)
         h = run_conv(self.conv_block2.block[0], h)

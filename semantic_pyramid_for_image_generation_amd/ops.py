@@ -323,12 +323,14 @@ def _workspace(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None):
+def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None, scale_ptr=0, res=None):
+    """`bias` is a tensor or a raw device address (the shift row of cached BatchNorm coefficients)."""
     mp = plan.mode(CONV_FWD)
     wp = _packed_weights(plan, w, CONV_FWD)
     y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device)
     ws = _workspace(mp.ws_bytes, x.device)
-    check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(), _p(bias), act_kind, slope,
+    check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(),
+                              bias if isinstance(bias, int) else _p(bias), scale_ptr, _p(res), act_kind, slope,
                               y.data_ptr(), _p(pooled), _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
     return y
 
@@ -712,12 +714,9 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, N):
     return coeffs
 
 
-def bn_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, res=None, act_kind=ACT_NONE, slope=0.0):
-    """Eval-mode BatchNorm2d (+ residual add + activation) with frozen statistics and parameters
-    (ResNet18 classifier, classifier.py:34 under .eval(); generator under `sample`, train_model.py:153).
-    The per-row coefficients only change when a parameter / buffer does, so they are cached on the weight tensor
-    (keyed by batch size and tensor versions): the frozen classifier computes them once."""
-    N = x.shape[0]
+def _bn_eval_cached(gamma, beta, running_mean, running_var, eps, N):
+    """Per-row (N*C) scale / shift of an eval-mode BatchNorm2d.  They only change when a parameter / buffer does, so they
+    are cached on the weight tensor (keyed by batch size and tensor versions): the frozen classifier computes them once."""
     key = (N, eps, gamma._version, beta._version, running_mean._version, running_var._version,
            gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr())
     hit = getattr(gamma, "_sempyr_bn_eval", None)
@@ -729,7 +728,77 @@ def bn_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, res=None, a
             gamma._sempyr_bn_eval = (key, coeffs)
         except Exception:  # pragma: no cover
             pass
+    return coeffs
+
+
+def bn_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, res=None, act_kind=ACT_NONE, slope=0.0):
+    """Eval-mode BatchNorm2d (+ residual add + activation) with frozen statistics and parameters
+    (ResNet18 classifier, classifier.py:34 under .eval(); generator under `sample`, train_model.py:153)."""
+    coeffs = _bn_eval_cached(gamma, beta, running_mean, running_var, eps, x.shape[0])
     return _apply(_AffineRowAct, x, res, coeffs, act_kind, slope)
+
+
+class _ConvBnEval(Function):
+    """y = act(BatchNorm_eval(conv2d(x[, upsampled x2], w)) [+ res]) in one launch: the norm's per-channel scale / shift,
+    the residual add and the activation run in the convolution's epilogue.  `coeffs` are constants, as in _AffineRowAct."""
+
+    @staticmethod
+    def forward(ctx, x, w, res, plan, coeffs, act_kind, slope):
+        x = _req(x, "conv input"); w = _req(w, "conv weight")
+        if res is not None:
+            res = _req(res, "residual")
+            if tuple(res.shape) != (plan.B, plan.Cout, plan.Ho, plan.Wo):
+                raise _lib.SempyrError("conv + BatchNorm: the residual must have the output's shape")
+        rows = plan.B * plan.Cout
+        if coeffs.numel() != 2 * rows:
+            raise _lib.SempyrError("conv + BatchNorm: coefficient table does not match the output")
+        y = _raw_conv_fwd(plan, x, w, coeffs.data_ptr() + 4 * rows, act_kind, slope, None, coeffs.data_ptr(), res)
+        ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None, coeffs)
+        ctx.plan = plan
+        ctx.cfg = (act_kind, slope, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y, coeffs = ctx.saved_tensors
+        plan = ctx.plan
+        act_kind, slope, has_res = ctx.cfg
+        if torch.is_grad_enabled() and gy.requires_grad:
+            raise NotImplementedError("double backward through eval-mode BatchNorm is not part of the hot path")
+        gy = _req(gy, "grad")
+        rows, HW = plan.B * plan.Cout, plan.Ho * plan.Wo
+        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not _INPUT_GRADS_ONLY
+        gres = torch.empty_like(gy) if (has_res and ctx.needs_input_grad[2]) else None
+        g = torch.empty_like(gy) if (want_x or want_w) else None
+        if g is None and gres is None:
+            return None, None, None, None, None, None, None
+        check(L.sempyr_affine_act_bwd(gy.data_ptr(), _p(y), coeffs.data_ptr(), _p(g), _p(gres), rows, HW, act_kind, slope,
+                                      _stream()), "sempyr_affine_act_bwd")
+        gx = gw = None
+        if want_w:
+            if _can_async(w, None, True, False):
+                _param_grads_async(g, x, plan, w, None, True, False)
+            else:
+                gw = _apply(_ConvWgrad, g, x, plan)
+        if want_x:
+            gx = _conv_input_grad(g, w, plan)
+        return gx, gw, gres, None, None, None, None
+
+
+def conv_bn_eval_act(x, w, gamma, beta, running_mean, running_var, eps=1e-5, stride=1, padding=0, upsample=False, res=None,
+                     act_kind=ACT_NONE, slope=0.0):
+    """Bias-free nn.Conv2d followed by an eval-mode nn.BatchNorm2d, an optional residual add and an activation — the
+    BasicBlock pattern of the frozen ResNet18 classifier (classifier.py:34-40) and the generator's ConvBlock / ResidualBlock
+    under .eval() (generator.py:27-29,54-57 from eval_model.py) — as a single convolution launch."""
+    B, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = w.shape
+    if Cin_w != Cin:
+        raise _lib.SempyrError(f"conv2d: weight expects {Cin_w} input channels, got {Cin}")
+    if gamma.numel() != Cout:
+        raise _lib.SempyrError(f"BatchNorm2d over {gamma.numel()} channels after a conv with {Cout} outputs")
+    plan = get_plan((B, Cin, H, W, Cout, kh, kw, stride, padding, 1 if upsample else 0), x.device)
+    coeffs = _bn_eval_cached(gamma, beta, running_mean, running_var, eps, B)
+    return _apply(_ConvBnEval, x, w, res, plan, coeffs, act_kind, slope)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ only hold parameters/buffers.
 import torch.nn as nn
 
 from . import ops
-from .blocks import run_conv, run_norm
+from .blocks import run_conv_norm
 
 
 class BasicBlock(nn.Module):
@@ -37,9 +37,9 @@ def run_basic_block(block, x):
     Works on any object with torchvision BasicBlock attributes."""
     identity = x
     if block.downsample is not None:
-        identity = run_norm(block.downsample[1], run_conv(block.downsample[0], x))
-    out = run_norm(block.bn1, run_conv(block.conv1, x), ops.ACT_RELU)
-    return run_norm(block.bn2, run_conv(block.conv2, out), ops.ACT_RELU, res=identity)
+        identity = run_conv_norm(block.downsample[0], block.downsample[1], x)
+    out = run_conv_norm(block.conv1, block.bn1, x, ops.ACT_RELU)
+    return run_conv_norm(block.conv2, block.bn2, out, ops.ACT_RELU, res=identity)
 
 
 class HipStage(nn.Sequential):

@@ -267,6 +267,59 @@ def test_bn_eval_act_residual(dev):
     assert rel_err(y, yr) < 1e-5 and rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(rd.grad, rr.grad) < 1e-5
 
 
+# conv -> eval BatchNorm -> (+ residual) -> activation as one launch: the single-pass MFMA kernels (generic gather, 3x3 patch
+# with and without the fused upsample), the split-K combine, a ragged M tile and the 7x7 stem
+@pytest.mark.parametrize("case", [(2, 64, 32, 32, 64, 3, 1, 1, 0), (2, 64, 16, 16, 64, 3, 1, 1, 1), (2, 64, 16, 16, 128, 3, 2, 1, 0),
+                                  (2, 64, 16, 16, 128, 1, 2, 0, 0), (1, 512, 8, 8, 512, 3, 1, 1, 0), (1, 5, 9, 11, 7, 3, 1, 1, 0),
+                                  (2, 3, 64, 64, 64, 7, 2, 3, 0), (2, 64, 16, 16, 64, 1, 1, 0, 1)])
+@pytest.mark.parametrize("with_res,act", [(True, 'relu'), (False, 'relu'), (False, 'none')])
+def test_conv_bn_eval_fused(dev, case, with_res, act):
+    ops = _ops()
+    B, Cin, H, W, Cout, k, s, p, ups = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    gam, bet = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    rm, rv = torch.randn(Cout, generator=g) * 0.2, torch.rand(Cout, generator=g) + 0.5
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode='nearest') if ups else xr
+    pre = F.batch_norm(F.conv2d(xin, wr, None, s, p), rm, rv, gam, bet, False, 0.1, 1e-5)
+    res = torch.randn(pre.shape, generator=g) if with_res else None
+    rr = res.clone().requires_grad_(True) if with_res else None
+    if with_res:
+        pre = pre + rr
+    yr = F.relu(pre) if act == 'relu' else pre
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
+    rd = res.to(dev).requires_grad_(True) if with_res else None
+    y = ops.conv_bn_eval_act(xd, wd, gam.to(dev), bet.to(dev), rm.to(dev), rv.to(dev), 1e-5, s, p, upsample=bool(ups), res=rd,
+                             act_kind=ops.ACT_RELU if act == 'relu' else ops.ACT_NONE)
+    assert y.shape == yr.shape
+    y.backward(gy.to(dev))
+    ops.join_side_streams()
+    tol = 2e-5
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+    if with_res:
+        assert rel_err(rd.grad, rr.grad) < tol
+    # the same call without autograd (eval_model.py runs under no_grad)
+    with torch.no_grad():
+        y2 = ops.conv_bn_eval_act(xd, wd, gam.to(dev), bet.to(dev), rm.to(dev), rv.to(dev), 1e-5, s, p, upsample=bool(ups),
+                                  res=rd, act_kind=ops.ACT_RELU if act == 'relu' else ops.ACT_NONE)
+    assert torch.equal(y2, y)
+
+
+def test_conv_bn_eval_rejects_small_heads(dev):
+    ops = _ops()
+    from semantic_pyramid_for_image_generation_amd._lib import SempyrError
+    x = torch.randn(1, 8, 16, 16, device=dev); w = torch.randn(3, 8, 3, 3, device=dev)
+    one = torch.ones(3, device=dev)
+    with pytest.raises(SempyrError):
+        ops.conv_bn_eval_act(x, w, one, one, one, one, 1e-5, 1, 1)
+
+
 def test_elementwise_and_pools(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(11)
