@@ -99,7 +99,7 @@ def main():
     ap.add_argument('--no-eval', action='store_true')
     a = ap.parse_args()
 
-    from semantic_pyramid_for_image_generation_amd import _lib, eval_model, ops, parallel
+    from semantic_pyramid_for_image_generation_amd import _lib, eval_model, ops, optim, parallel
     from semantic_pyramid_for_image_generation_amd import train_model as tm
     device = parallel.init_device()
     rank, world = parallel.rank(), parallel.world_size()
@@ -111,8 +111,8 @@ def main():
     tm.args = Namespace(use_diversity_loss=a.use_diversity_loss, gradient_penalty_weight=10.0)
     d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
     crit = tm.L1Loss()
-    g_opt = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    d_opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
     normalizer_clf = tm.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     normalizer_d = tm.Normalize([0.5, 0.5, 0.5], [0.5, 0.5, 0.5])
 

@@ -164,6 +164,21 @@ int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_ro
 int sempyr_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
 /* y = alpha*a + beta*b (b may be NULL) : gradient accumulation / scaling glue */
 int sempyr_axpby(const float* a, const float* b, float alpha, float beta, float* y, int64_t n, void* stream);
+/* Multi-tensor Adam step: optim.Adam(lr=2e-4, betas=(.5,.999)) train_model.py:273-274, .step() at :117,143 (eps 1e-8, no
+ * weight decay, no amsgrad).  `tensors` is a HOST array (it travels in the kernel arguments, SEMPYR_ADAM_MAX_TENSORS per
+ * launch); `step` is the 1-based step count shared by all listed tensors; grad is read as grad*grad_scale (1/N of a summed
+ * data-parallel gradient) and overwritten with zeros when zero_grads != 0.  Operation order follows torch's foreach Adam:
+ * m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
+#define SEMPYR_ADAM_MAX_TENSORS 64
+typedef struct sempyr_adam_tensor {
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} sempyr_adam_tensor;
+int sempyr_adam_step(const sempyr_adam_tensor* tensors, int n_tensors, int64_t step, double lr, double beta1, double beta2,
+                     double eps, double grad_scale, int zero_grads, void* stream);
 /* out = real + alpha_row[r]*(fake-real) : sample_line train_model.py:51-55 */
 int sempyr_lerp_rows(const float* real, const float* fake, const float* alpha_row, float* out,
                      int rows, int len, void* stream);

@@ -34,6 +34,13 @@ class ConvPlanInfo(ctypes.Structure):
                 ("splits", ctypes.c_int32 * MAX_PHASES), ("cfg", ctypes.c_int32)]
 
 
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("numel", ctypes.c_int64)]
+
+
+ADAM_MAX_TENSORS = 64
+
 _P = c_void_p  # every device / host pointer is passed as an integer address
 _DESC = ctypes.POINTER(ConvDesc)
 
@@ -56,6 +63,8 @@ SIGNATURES = {
     "sempyr_affine_act_bwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
     "sempyr_mul": [_P, _P, _P, c_int64, _P],
     "sempyr_axpby": [_P, _P, c_float, c_float, _P, c_int64, _P],
+    "sempyr_adam_step": [ctypes.POINTER(AdamTensor), c_int, c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                         ctypes.c_double, ctypes.c_double, c_int, _P],
     "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],
     "sempyr_normalize": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "sempyr_pool2_down": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],

@@ -1,0 +1,98 @@
+"""`optim.Adam` of the train scripts (train_model.py:273-274, train_feature_creation_gen.py:157-160) as ONE HIP launch per
+step for all parameter tensors of a module, instead of torch's ~7 multi-tensor launches.
+
+Same constructor arguments, `param_groups` keys and per-parameter state (`step`, `exp_avg`, `exp_avg_sq`) as
+`torch.optim.Adam`, so `state_dict()` / `load_state_dict()` interoperate with it in both directions.  Only what the
+reference uses is implemented on the GPU path (no weight decay, no amsgrad, no maximize); asking for anything else raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+L = _lib.lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, *, maximize=False,
+                 grad_scale=1.0, zero_grads=False):
+        if weight_decay != 0 or amsgrad or maximize:
+            raise NotImplementedError("weight_decay / amsgrad / maximize are not used by the reference and have no HIP kernel")
+        if not 0.0 <= lr:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if not 0.0 <= eps:
+            raise ValueError(f"Invalid epsilon value: {eps}")
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f"Invalid beta parameters: {betas}")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize,
+                        foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
+        super().__init__(params, defaults)
+        # grad is read as grad * grad_scale (e.g. 1/N of a summed data-parallel gradient); zero_grads: the kernel leaves
+        # zeros in .grad (for callers that keep persistent gradient buffers instead of zero_grad(set_to_none=True))
+        self.grad_scale = float(grad_scale)
+        self.zero_grads = bool(zero_grads)
+        self._tables = {}
+
+    def _table(self, key, entries):
+        """ctypes tensor table for one (group, step) cohort; param / state pointers are stable, gradients are re-read."""
+        hit = self._tables.get(key)
+        n = len(entries)
+        if hit is None or hit[1] != n:
+            arr = (_lib.AdamTensor * n)()
+            hit = (arr, n)
+            self._tables[key] = hit
+        arr = hit[0]
+        for i, (p, g, m, v) in enumerate(entries):
+            t = arr[i]
+            t.param = p.data_ptr(); t.grad = g.data_ptr(); t.exp_avg = m.data_ptr(); t.exp_avg_sq = v.data_ptr()
+            t.numel = p.numel()
+        return arr
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            if group['weight_decay'] != 0 or group['amsgrad'] or group.get('maximize', False):
+                raise NotImplementedError("weight_decay / amsgrad / maximize have no HIP kernel")
+            beta1, beta2 = group['betas']
+            cohorts = {}                       # step count -> tensors (one cohort unless some parameter skipped steps)
+            steps = []
+            for p in group['params']:
+                g = p.grad
+                if g is None:
+                    continue
+                if g.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients")
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise _lib.SempyrError("optim.Adam: parameters must be contiguous fp32 tensors on the GPU (no CPU fallback)")
+                if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape):
+                    g = g.to(device=p.device, dtype=torch.float32).contiguous()
+                    p.grad = g
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                steps.append(st['step'])
+                cohorts.setdefault(int(st['step']) + 1, []).append((p, g, st['exp_avg'], st['exp_avg_sq']))
+            if not steps:
+                continue
+            torch._foreach_add_(steps, 1)
+            for t, entries in cohorts.items():
+                dev = entries[0][0].device
+                if any(e[0].device != dev for e in entries):
+                    raise _lib.SempyrError("optim.Adam: the parameters of one group must live on one GPU")
+                arr = self._table((gi, len(cohorts) > 1 and t), entries)
+                stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+                with torch.cuda.device(dev):
+                    _lib.check(L.sempyr_adam_step(arr, len(entries), t, float(group['lr']), float(beta1), float(beta2),
+                                                  float(group['eps']), self.grad_scale, 1 if self.zero_grads else 0, stream),
+                               "sempyr_adam_step")
+                # the kernel wrote through raw pointers: bump the autograd version counters (packed-weight and
+                # eval-BatchNorm caches are keyed on them)
+                torch.autograd.graph.increment_version([e[0] for e in entries])
+        return loss

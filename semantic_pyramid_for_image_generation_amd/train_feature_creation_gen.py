@@ -5,7 +5,7 @@ import os
 import time
 
 import torch
-import torch.optim as optim
+from . import optim
 
 from . import ops, parallel
 from .featuresCreatorGen import Features1ToImage, FeaturesDiscriminator, LevelUpFeaturesGenerator

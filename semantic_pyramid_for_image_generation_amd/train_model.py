@@ -15,7 +15,7 @@ import time
 
 import torch
 import torch.nn as nn
-import torch.optim as optim
+from . import optim
 
 from . import ops, parallel
 from .classifier import Classifier  # noqa: F401

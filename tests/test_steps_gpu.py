@@ -30,8 +30,14 @@ from golden_util import cpu_state, load_json, load_npz
 from oracle import masks as omasks
 from oracle import nets, recipes
 
-pytestmark = pytest.mark.gpu
 
+def _Adam(params, **kw):
+    """the package's single-launch HIP Adam (what train_model._main constructs)"""
+    from semantic_pyramid_for_image_generation_amd import optim
+    return optim.Adam(params, **kw)
+
+
+pytestmark = pytest.mark.gpu
 
 
 def _grad_close(name, got, want, global_max):
@@ -86,7 +92,7 @@ def test_d_step_gradients_vs_oracle(dev, case):
     gen_type, norm, div = case
     tm, G, D, C, tr, images, feats, masks, z, z2, alpha = _setup(dev, gen_type, norm, div, 71)
     d_loss_fn, _ = tm.get_wgan_losses_fn()
-    d_opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    d_opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
     want = tr.d_step(_d((images - 0.5) / 0.5), _d(feats), _d(masks), _d(z), _d(alpha))
     got = tm.train_discriminator(G, D, d_loss_fn, d_opt, ((images - 0.5) / 0.5).to(dev), [f.to(dev) for f in feats],
                                  [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
@@ -104,7 +110,7 @@ def test_g_step_gradients_vs_oracle(dev, case):
     tm, G, D, C, tr, images, feats, masks, z, z2, alpha = _setup(dev, gen_type, norm, div, 72)
     _, g_loss_fn = tm.get_wgan_losses_fn()
     crit = tm.L1Loss()
-    g_opt = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g_opt = _Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     want = tr.g_step(_d(feats), _d(masks), 3, _d(z), _d(z2) if div else None)
     got = tm.train_generator(G, D, g_loss_fn, g_opt, 2, [f.to(dev) for f in feats], crit, 3, C,
                              tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD), crit, crit, [m.to(dev) for m in masks], [2],
@@ -147,8 +153,8 @@ def test_train_steps(dev, case):
     tm.args = Namespace(use_diversity_loss=div, gradient_penalty_weight=10.0)
     d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
     crit = tm.L1Loss()
-    g_opt = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    d_opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g_opt = _Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    d_opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
     images = recipes.image_batch(seed, 2).to(dev)
     normalizer_clf = tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD)
     normalizer_d = tm.Normalize([0.5, 0.5, 0.5], [0.5, 0.5, 0.5])
@@ -200,8 +206,8 @@ def test_feature_gen_steps(dev):
     tf.args = Namespace(gradient_penalty_weight=10.0)
     d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
     crit = tm.L1Loss()
-    g_opt = torch.optim.Adam(FG.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    d_opt = torch.optim.Adam(FD.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g_opt = _Adam(FG.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    d_opt = _Adam(FD.parameters(), lr=2e-4, betas=(0.5, 0.999))
     images = recipes.image_batch(seed, 2).to(dev)
     with torch.no_grad():
         _, features = C(tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD)(images))
@@ -236,7 +242,7 @@ def test_stream_overlap_matches_single_stream(dev):
         ops.TWO_STREAM_CRITIC = ops._ASYNC_ENV = overlap
         try:
             D.load_state_dict(state)
-            opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
             out = tm.train_discriminator(G, D, d_loss_fn, opt, *args, z=z.to(dev), alpha=alpha.to(dev))
             torch.cuda.synchronize()
             return ({k: float(v) for k, v in out.items()}, {k: p.grad.detach().clone() for k, p in D.named_parameters()})
@@ -273,8 +279,8 @@ def test_prefetched_iterations_match_in_place(dev):
         ops.PREFETCH = prefetch_on
         try:
             G.load_state_dict(gstate); D.load_state_dict(dstate)
-            d_opt = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
-            g_opt = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            d_opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            g_opt = _Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
             torch.manual_seed(5); rnd = random.Random(5)
             losses = []
             for it in range(1, 4):
