@@ -1082,16 +1082,36 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------
 enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3, CFG_64x192 = 4, CFG_64x128 = 5 };
 
-inline int pick_cfg(int Mpad, long long N = 1ll << 40) {
-    if (Mpad % 128 == 0) return CFG_128x128;
+// Tile shape for a GATHER launch over N pixels (all stride phases of a DGRAD together).  `kind`: the kernel the launch
+// will run on — the choices below are measured (tools/bench_conv.py mid / small with SEMPYR_FORCE_CFG*).
+enum { KIND_GENERIC_FWD = 0, KIND_PATCH3X3 = 1, KIND_DGRAD = 2, KIND_ANY = 3 };
+inline int pick_cfg(int Mpad, long long N = 1ll << 40, int kind = KIND_ANY) {
+    if (Mpad % 128 == 0) {
+        // few 128x128 tiles mean deep split-K (slab writes + a combine pass per launch): 64x64 tiles need a quarter of the
+        // splits. Measured at batch 16: 3x3 128->128 @32^2 0.060 -> 0.048 ms, 512->512 @8^2 0.062 -> 0.051, input gradient
+        // of the critic's 512->512 4x4 s2 block 0.059 -> 0.041; the forward 4x4 s2 blocks with 32..128 tiles prefer 128x128.
+        const long long t128 = (Mpad / 128) * ((N + 127) / 128);
+        if (t128 < 512 && (kind == KIND_PATCH3X3 || kind == KIND_DGRAD)) return CFG_64x64;
+        if (t128 < 16 && kind == KIND_GENERIC_FWD) return CFG_64x64;
+        return CFG_128x128;
+    }
     if (Mpad % 64 == 0) {
-        // mid-size pixel counts (64 channels at 64x64 x batch 16): 64x64 tiles fill the chip without split-K slabs and
-        // their combine pass (measured 0.121 -> 0.103 ms on the critic's 64->64 4x4 s2 block)
-        const long long t256 = (Mpad / 64) * ((N + 255) / 256), t64 = (Mpad / 64) * ((N + 63) / 64);
+        // mid-size pixel counts (64 channels at 64x64 x batch 16): narrower tiles fill the chip without split-K slabs and
+        // their combine pass (measured 0.121 -> 0.103 ms on the critic's 64->64 4x4 s2 block; the 3x3 patch kernel is
+        // another 6-8 % faster on 64x128 tiles when those already give 512 workgroups)
+        const long long t256 = (Mpad / 64) * ((N + 255) / 256), t128 = (Mpad / 64) * ((N + 127) / 128),
+                        t64 = (Mpad / 64) * ((N + 63) / 64);
+        if (t256 < 512 && t128 >= 512 && kind == KIND_PATCH3X3) return CFG_64x128;
         if (t256 < 512 && t64 >= 512) return CFG_64x64;
         return CFG_64x256;
     }
     return CFG_32x256;
+}
+inline int conv_kind(const sempyr_conv_desc* d, int mode) {
+    if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && !(mode == SEMPYR_CONV_DGRAD && d->ups) &&
+        (mode == SEMPYR_CONV_FWD ? d->Cin : d->Cout) % 8 == 0)
+        return KIND_PATCH3X3;
+    return mode == SEMPYR_CONV_DGRAD ? KIND_DGRAD : KIND_GENERIC_FWD;
 }
 inline void cfg_dims(int cfg, int& bm, int& bn) {
     if (cfg == CFG_128x128) { bm = 128; bn = 128; }
@@ -1386,7 +1406,7 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         plan->K[0] = d->Cin * g.T; plan->Kpad[0] = (plan->K[0] + BK - 1) / BK * BK;
         plan->tab_off[0] = 0; plan->tab_entries = plan->Kpad[0];
         plan->Mpad = (d->Cout + 31) / 32 * 32;
-        plan->cfg = pick_cfg(plan->Mpad, (long long)d->B * g.Ho * g.Wo);
+        plan->cfg = pick_cfg(plan->Mpad, (long long)d->B * g.Ho * g.Wo, conv_kind(d, mode));
         { static const int f = env_int("SEMPYR_FORCE_CFG", -1); if (f >= 0 && plan->Mpad % (f == CFG_128x128 ? 128 : f == CFG_32x256 ? 32 : 64) == 0) plan->cfg = f; }
         cfg_dims(plan->cfg, bm, bn);
         plan->wpack_floats = (long long)plan->Kpad[0] * plan->Mpad;
@@ -1399,7 +1419,9 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         const int s = d->stride;
         plan->nphases = s * s;
         plan->Mpad = (d->Cin + 31) / 32 * 32;
-        plan->cfg = pick_cfg(plan->Mpad); cfg_dims(plan->cfg, bm, bn);
+        plan->cfg = pick_cfg(plan->Mpad, in_numel / d->Cin, conv_kind(d, mode));
+        { static const int f = env_int("SEMPYR_FORCE_CFG_DGRAD", -1); if (f >= 0 && plan->Mpad % (f == CFG_128x128 ? 128 : f == CFG_32x256 ? 32 : 64) == 0) plan->cfg = f; }
+        cfg_dims(plan->cfg, bm, bn);
         int off = 0, max_splits = 1;
         for (int py = 0; py < s; ++py) for (int px = 0; px < s; ++px) {
             const int ph = py * s + px;
@@ -1428,7 +1450,9 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         const int Nn = (d->Cin * g.T + BK - 1) / BK * BK;       // = FWD Kpad: columns incl. padding
         plan->tab_off[0] = 0; plan->tab_entries = Nn;
         plan->Mpad = (d->Cout + 31) / 32 * 32;
-        plan->cfg = pick_cfg_wgrad(plan->Mpad, Nn, d->Cin % BK == 0); cfg_dims(plan->cfg, bm, bn);
+        plan->cfg = pick_cfg_wgrad(plan->Mpad, Nn, d->Cin % BK == 0);
+        { static const int f = env_int("SEMPYR_FORCE_CFG_WGRAD", -1); if (f >= 0 && f != CFG_64x192 && plan->Mpad % (f == CFG_128x128 ? 128 : f == CFG_32x256 ? 32 : 64) == 0) plan->cfg = f; }
+        cfg_dims(plan->cfg, bm, bn);
         plan->wpack_floats = 0;
         int cps;
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(Nn, bn), plan->Kpad[0] / BK, plan->splits[0], cps, target_blocks_wgrad());
