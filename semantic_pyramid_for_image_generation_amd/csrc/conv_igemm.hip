@@ -1137,7 +1137,7 @@ inline int target_blocks() { static const int v = env_int("SEMPYR_TARGET_BLOCKS"
 // WGRAD reduces over all pixels (K up to 2^20) into a handful of tiles: 3 workgroups per CU (768) balance better than 2
 // (measured 0.98 -> 0.82 ms on the 64x576x2^20 problem), while the short-K forward / input-gradient launches prefer 512.
 inline int target_blocks_wgrad() { static const int v = env_int("SEMPYR_TARGET_BLOCKS_WGRAD", 768); return v; }
-inline int min_chunks() { static const int v = env_int("SEMPYR_MIN_CHUNKS", 4); return v; }
+inline int min_chunks() { static const int v = env_int("SEMPYR_MIN_CHUNKS", 8); return v; }
 
 inline void pick_splits(int tiles, int nchunks, int& splits, int& cps, int target = 0) {
     if (target <= 0) target = target_blocks();
