@@ -98,6 +98,9 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
     a = ap.parse_args()
+    if os.environ.get('SEMPYR_BENCH_TRACE'):          # debugging aid: where is every thread after N seconds?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['SEMPYR_BENCH_TRACE']), exit=True)
 
     from semantic_pyramid_for_image_generation_amd import _lib, eval_model, ops, optim, parallel
     from semantic_pyramid_for_image_generation_amd import train_model as tm
@@ -184,7 +187,7 @@ def main():
         _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
         ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH = saved
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if torch.distributed.get_backend() == 'gloo' else device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -202,7 +205,7 @@ def main():
         torch.cuda.synchronize()
         eval_ips = reps * 128 / (time.perf_counter() - t1)
         if world > 1:
-            t = torch.tensor([eval_ips], dtype=torch.float64, device=device)
+            t = torch.tensor([eval_ips], dtype=torch.float64, device='cpu' if torch.distributed.get_backend() == 'gloo' else device)
             torch.distributed.all_reduce(t)
             eval_ips = float(t.item())
 

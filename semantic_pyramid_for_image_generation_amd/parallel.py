@@ -37,27 +37,54 @@ def init_device(backend=None):
     if not torch.cuda.is_available():
         raise RuntimeError("the sempyr hot path needs a GPU (no CPU fallback)")
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = backend or os.environ.get('SEMPYR_DIST_BACKEND', 'nccl')
+    if os.environ.get('SEMPYR_SHARE_GPU', '0') == '1':
+        # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device,
+        # so this needs SEMPYR_DIST_BACKEND=gloo); never used for measurements
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
-        dist.init_process_group(backend or 'nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     return torch.device('cuda', local)
 
 
+def _host_staged():
+    """gloo moves device tensors through the host anyway; staging them explicitly keeps its CUDA path (which hangs when two
+    rehearsal ranks share one GPU) out of the picture.  RCCL works on device memory directly."""
+    return dist.get_backend() == 'gloo'
+
+
 def broadcast_module(module, src=0):
-    """Make parameters and buffers identical on all ranks (rank `src` wins)."""
+    """Make parameters and buffers identical on all ranks (rank `src` wins): one flat collective per dtype."""
     if not is_distributed():
         return
+    by_dtype = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for tensors in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        if flat.is_cuda and _host_staged():
+            host = flat.cpu()
+            dist.broadcast(host, src)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
 
 def _flat_buffer(params):
-    key = tuple(id(p) for p in params)
-    buf = _FLAT.get(key)
+    # keyed by size, not by tensor identity: gradient tensors are new allocations every step
     n = sum(p.numel() for p in params)
-    if buf is None or buf.numel() != n or buf.device != params[0].device:
+    key = (n, params[0].dtype, params[0].device)
+    buf = _FLAT.get(key)
+    if buf is None:
         buf = torch.empty(n, dtype=params[0].dtype, device=params[0].device)
-        _FLAT.clear() if len(_FLAT) > 8 else None
         _FLAT[key] = buf
     return buf
 
@@ -74,7 +101,12 @@ def allreduce_mean_(tensors, group=None):
         views.append(flat[off:off + t.numel()].view_as(t))
         off += t.numel()
     torch._foreach_copy_(views, tensors)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and _host_staged():
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.mul_(1.0 / ws)
     torch._foreach_copy_(tensors, views)
 

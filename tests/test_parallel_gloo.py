@@ -18,12 +18,14 @@ def _worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from semantic_pyramid_for_image_generation_amd import parallel
     torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2), torch.nn.BatchNorm1d(3))
     if rank == 1:                                    # diverge, then broadcast must repair it
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(1.0)
+            net[3].running_mean.add_(2.0); net[3].num_batches_tracked.add_(7)      # buffers (float and int64) too
     parallel.broadcast_module(net)
+    assert float(net[3].running_mean.abs().max()) == 0.0 and int(net[3].num_batches_tracked) == 0
     opt = torch.optim.Adam(net.parameters(), lr=1e-2, betas=(0.5, 0.999))
     g = torch.Generator().manual_seed(10 + rank)     # rank-distinct data
     x = torch.randn(4, 6, generator=g)
