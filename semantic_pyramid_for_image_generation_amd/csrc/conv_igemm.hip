@@ -1451,6 +1451,11 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         plan->tab_off[0] = 0; plan->tab_entries = Nn;
         plan->Mpad = (d->Cout + 31) / 32 * 32;
         plan->cfg = pick_cfg_wgrad(plan->Mpad, Nn, d->Cin % BK == 0);
+        // mid-size reductions (<= 2^17 pixels: the critic's blocks, the deep generator / classifier layers): 64x128 tiles
+        // double the tile count, i.e. halve the split-K depth and the slabs the combine pass reads (measured 4-10 % on
+        // the critic's 64->64 and 64->128 4x4 blocks, neutral elsewhere)
+        if ((plan->cfg == CFG_128x128 || plan->cfg == CFG_64x256) && plan->K[0] <= (1 << 17) && Nn % 128 == 0)
+            plan->cfg = CFG_64x128;
         { static const int f = env_int("SEMPYR_FORCE_CFG_WGRAD", -1); if (f >= 0 && f != CFG_64x192 && plan->Mpad % (f == CFG_128x128 ? 128 : f == CFG_32x256 ? 32 : 64) == 0) plan->cfg = f; }
         cfg_dims(plan->cfg, bm, bn);
         plan->wpack_floats = 0;
