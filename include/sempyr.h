@@ -101,9 +101,11 @@ int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, const float*
                         const int32_t* ktab_dgrad_dev, const float* bias, float* gx,
                         void* workspace, size_t workspace_bytes, void* stream);
 
-/* gw[Cout,Cin,kh,kw] = sum_{b,oy,ox} gy * x (deterministic split-K, fixed summation order). */
+/* gw[Cout,Cin,kh,kw] = sum_{b,oy,ox} gy * x (deterministic split-K, fixed summation order); accumulate != 0: gw += that
+ * sum (autograd's gradient accumulation for a weight used by several passes of one step — D(real), D(fake), D(x_hat) at
+ * train_model.py:128-137 — folded into the combine pass instead of a separate add). */
 int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, const float* x,
-                        const int32_t* ktab_fwd_dev, float* gw,
+                        const int32_t* ktab_fwd_dev, float* gw, int accumulate,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 
@@ -215,8 +217,9 @@ int sempyr_l1_mean_bwd(const float* a, const float* b, const float* mask, const 
 int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, void* stream);
 /* out = grad * (*gout) * (2/rows) * (norm-1)/norm : its backward (feeds the double backward) */
 int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int rows, int len, float* out, void* stream);
-/* out[c] = scale * sum_{n,hw} x[n][c][hw] : conv bias gradient ; scratch = N*C floats */
-int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, float* scratch, void* stream);
+/* out[c] = scale * sum_{n,hw} x[n][c][hw] : conv bias gradient ; scratch = N*C floats ; accumulate != 0: out[c] += that */
+int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, int accumulate, float* scratch,
+                       void* stream);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -53,7 +53,7 @@ SIGNATURES = {
     "sempyr_conv2d_pack_weights": [_DESC, c_int, _P, _P, _P, _P],
     "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
-    "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, _P, c_size_t, _P],
+    "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, _P, c_size_t, _P],
     "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, _P, _P],
     "sempyr_bn_eval_coeffs": [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P],
     "sempyr_norm_bwd": [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
@@ -78,7 +78,7 @@ SIGNATURES = {
     "sempyr_l1_mean_bwd": [_P, _P, _P, _P, c_int64, _P, _P, _P],
     "sempyr_gp_fwd": [_P, c_int, c_int, _P, _P, _P],
     "sempyr_gp_bwd": [_P, _P, _P, c_int, c_int, _P, _P],
-    "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, _P, _P],
+    "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P],
     "sempyr_profile_begin": [c_int],
     "sempyr_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
 }

@@ -1007,7 +1007,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_tail_kernel(const float* __
 // gw[co][ci][tap] = sum_s slab[s][co][n = tap*Cin + ci]   -- WGRAD combine + re-layout to torch order.
 // Threads walk the slab layout (n fastest) so the `splits` reads are coalesced; the single write is the scattered one.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
-                                                           int splits, long long slab_stride, int M, int Cin, int T, int ldc)
+                                                           int splits, long long slab_stride, int M, int Cin, int T, int ldc,
+                                                           int accumulate)
 {
     const int N = Cin * T;
     const int i = blockIdx.x * 256 + threadIdx.x;        // index in GEMM layout: m * N + n
@@ -1026,7 +1027,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         a3 += slabs[(size_t)(k + 3) * slab_stride + src];
     }
     for (; k < splits; ++k) a0 += slabs[(size_t)k * slab_stride + src];
-    gw[(size_t)m * N + ci * T + tap] = (a0 + a1) + (a2 + a3);
+    const size_t dst = (size_t)m * N + ci * T + tap;
+    const float sum = (a0 + a1) + (a2 + a3);
+    gw[dst] = accumulate ? gw[dst] + sum : sum;                // accumulate: gw += this launch's gradient
 }
 
 // The same for many slabs (thin problems reduce over 2^20 pixels in 500+ splits): 16 consecutive outputs (one 64-B
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // (1728 outputs x 512 slabs took 42 us as one dependent chain per thread). Fixed summation order: deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
                                                                 int splits, long long slab_stride, int M, int Cin, int T,
-                                                                int ldc)
+                                                                int ldc, int accumulate)
 {
     __shared__ float sh[16][17];
     const int N = Cin * T;
@@ -1062,7 +1065,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const float* __r
         for (int g = 0; g < 16; ++g) t += sh[g][threadIdx.x];
         const int tap = n / Cin;
         const int ci = n - tap * Cin;
-        gw[(size_t)m * N + ci * T + tap] = t;
+        const size_t dst = (size_t)m * N + ci * T + tap;
+        gw[dst] = accumulate ? gw[dst] + t : t;
     }
 }
 
@@ -1667,7 +1671,7 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
 }
 
 extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, const float* x,
-                                   const int32_t* ktab, float* gw,
+                                   const int32_t* ktab, float* gw, int accumulate,
                                    void* ws, size_t ws_bytes, void* stream)
 {
     sempyr_conv_plan pl;
@@ -1695,10 +1699,10 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     const int total = d->Cout * d->Cin * T;
     if (splits >= 64)
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(ceil_div(total, 16)), dim3(256), 0, st,
-                           (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn);
+                           (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st,
-                           (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn);
+                           (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }

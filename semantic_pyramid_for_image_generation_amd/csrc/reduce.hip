@@ -159,13 +159,14 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ 
 }
 
 // out[c] = scale * sum_n rs[n*C + c]
-__global__ void channel_fold_kernel(const float* __restrict__ rs, int N, int C, float scale, float* __restrict__ out)
+__global__ void channel_fold_kernel(const float* __restrict__ rs, int N, int C, float scale, float* __restrict__ out,
+                                    int accumulate)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float a = 0.f;
     for (int n = 0; n < N; ++n) a += rs[n * C + c];
-    out[c] = a * scale;
+    out[c] = accumulate ? out[c] + a * scale : a * scale;
 }
 
 template <int OP>
@@ -243,7 +244,8 @@ extern "C" int sempyr_gp_bwd(const float* grad, const float* norms, const float*
     return 0;
 }
 
-extern "C" int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, float* scratch, void* stream)
+extern "C" int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, int accumulate,
+                                  float* scratch, void* stream)
 {
     if (!x || !out || !scratch || N < 1 || C < 1 || HW < 1) SEMPYR_FAIL("channel_sum: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -252,7 +254,7 @@ extern "C" int sempyr_channel_sum(const float* x, int N, int C, int HW, float sc
     if (HW >= 2048) hipLaunchKernelGGL(row_sum_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, HW, vec, scratch);
     else hipLaunchKernelGGL(row_sum_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, HW, vec, scratch);
     SEMPYR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(channel_fold_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, N, C, scale, out);
+    hipLaunchKernelGGL(channel_fold_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, N, C, scale, out, accumulate ? 1 : 0);
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }

@@ -182,6 +182,18 @@ def _accumulate_grad(param, g, main):
         param.grad.add_(g)
 
 
+_INPLACE_GRAD = os.environ.get("SEMPYR_INPLACE_GRAD", "1") != "0"
+
+
+def _grad_in_place(param):
+    """param.grad when a kernel may add to it in place (a plain dense fp32 tensor of the parameter's shape), else None."""
+    g = param.grad
+    if (_INPLACE_GRAD and g is not None and g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == param.shape
+            and not g.requires_grad):
+        return g
+    return None
+
+
 _STREAM_OBJ = {}
 
 
@@ -203,10 +215,20 @@ def _param_grads_async(gy, x, plan, w, bias, want_w, want_b):
     side.wait_stream(main)
     torch.cuda.set_stream(side)            # (the `with torch.cuda.stream(...)` context costs ~40 us of host time)
     try:
+        # a weight used by several passes of one step (D(real,fake), D(x_hat)): later contributions are added to .grad by
+        # the reduction kernel itself instead of a separate add launch
         if want_w:
-            _accumulate_grad(w, _raw_conv_wgrad(plan, gy, x), main)
+            cur = _grad_in_place(w)
+            if cur is not None:
+                _raw_conv_wgrad(plan, gy, x, into=cur)
+            else:
+                _accumulate_grad(w, _raw_conv_wgrad(plan, gy, x), main)
         if want_b:
-            _accumulate_grad(bias, _channel_sum_raw(gy), main)
+            cur = _grad_in_place(bias)
+            if cur is not None:
+                _channel_sum_raw(gy, into=cur)
+            else:
+                _accumulate_grad(bias, _channel_sum_raw(gy), main)
     finally:
         torch.cuda.set_stream(main)
     gy.record_stream(side)
@@ -346,22 +368,24 @@ def _raw_conv_dgrad(plan, gy, w, bias):
     return gx
 
 
-def _raw_conv_wgrad(plan, gy, x):
+def _raw_conv_wgrad(plan, gy, x, into=None):
+    """`into`: an existing gradient tensor the result is added to in place (by the combine pass, no extra launch)."""
     mp = plan.mode(CONV_WGRAD)
-    gw = torch.empty((plan.Cout, plan.Cin, plan.kh, plan.kw), dtype=torch.float32, device=gy.device)
+    gw = into if into is not None else torch.empty((plan.Cout, plan.Cin, plan.kh, plan.kw), dtype=torch.float32,
+                                                   device=gy.device)
     ws = _workspace(mp.ws_bytes, gy.device)
     check(L.sempyr_conv2d_wgrad(plan.desc_ref, gy.data_ptr(), x.data_ptr(), mp.ktab.data_ptr(), gw.data_ptr(),
-                                _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_wgrad")
+                                0 if into is None else 1, _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_wgrad")
     return gw
 
 
-def _channel_sum_raw(g, scale=1.0):
+def _channel_sum_raw(g, scale=1.0, into=None):
     N, C = g.shape[0], g.shape[1]
     HW = g.numel() // (N * C)
-    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    out = into if into is not None else torch.empty(C, dtype=torch.float32, device=g.device)
     scratch = torch.empty(N * C, dtype=torch.float32, device=g.device)
-    check(L.sempyr_channel_sum(g.data_ptr(), N, C, HW, scale, out.data_ptr(), scratch.data_ptr(), _stream()),
-          "sempyr_channel_sum")
+    check(L.sempyr_channel_sum(g.data_ptr(), N, C, HW, scale, out.data_ptr(), 0 if into is None else 1, scratch.data_ptr(),
+                               _stream()), "sempyr_channel_sum")
     return out
 
 
@@ -1008,7 +1032,7 @@ def global_avg_pool(x):
     out = torch.empty(N * C, dtype=torch.float32, device=x.device)
     scratch = torch.empty(N * C, dtype=torch.float32, device=x.device)
     # channel_sum over a (1, N*C, HW) view = per-row sums
-    check(L.sempyr_channel_sum(x.data_ptr(), 1, N * C, HW, 1.0 / HW, out.data_ptr(), scratch.data_ptr(), _stream()),
+    check(L.sempyr_channel_sum(x.data_ptr(), 1, N * C, HW, 1.0 / HW, out.data_ptr(), 0, scratch.data_ptr(), _stream()),
           "sempyr_channel_sum")
     return out.view(N, C, 1, 1)
 

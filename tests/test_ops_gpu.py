@@ -320,6 +320,27 @@ def test_conv_bn_eval_rejects_small_heads(dev):
         ops.conv_bn_eval_act(x, w, one, one, one, one, 1e-5, 1, 1)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 16, 16, 128, 4, 2, 1, 0), (1, 5, 9, 11, 7, 3, 1, 1, 0), (2, 64, 64, 64, 64, 3, 1, 1, 0)])
+def test_wgrad_and_bias_grad_accumulate_in_place(dev, case):
+    """`accumulate` of sempyr_conv2d_wgrad / sempyr_channel_sum: gw += wgrad(gy, x) equals a separate add, bit for bit
+    (few- and many-slab combine kernels)."""
+    ops = _ops()
+    B, Cin, H, W, Cout, k, s, p, ups = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    plan = ops.get_plan((B, Cin, H, W, Cout, k, k, s, p, ups), dev)
+    gy = torch.randn(B, Cout, plan.Ho, plan.Wo, generator=g).to(dev)
+    old = torch.randn(Cout, Cin, k, k, generator=g).to(dev)
+    fresh = ops._raw_conv_wgrad(plan, gy, x)
+    acc = old.clone()
+    out = ops._raw_conv_wgrad(plan, gy, x, into=acc)
+    assert out is acc and torch.equal(acc, old + fresh)
+    oldb = torch.randn(Cout, generator=g).to(dev)
+    accb = oldb.clone()
+    ops._channel_sum_raw(gy, into=accb)
+    assert torch.equal(accb, oldb + ops._channel_sum_raw(gy))
+
+
 def test_elementwise_and_pools(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(11)
