@@ -126,6 +126,13 @@ int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                       float* rowbuf, float* scratch, void* stream);
 
+/* sempyr_norm_stats + the apply pass y = act((x - mean)*rstd*gamma + beta) as one call; InstanceNorm2d rows of up to 16384
+ * elements (every critic layer, discriminator.py:16-26) run as ONE launch that reads x from HBM once. scratch: 2*N*C floats. */
+int sempyr_norm_fwd(int kind, const float* x, int N, int C, int HW, float eps,
+                    const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                    int act, float slope, float* y, float* rowbuf, float* scratch, void* stream);
+
 /* eval-mode BatchNorm2d (classifier.py:34 with .eval(), train_model.py:153): per-row scale/shift
  * from the running statistics. */
 int sempyr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,

@@ -10,6 +10,7 @@
 // (wavefront shuffle reductions), and the per-kind logic lives in tiny "finalize" kernels that
 // turn per-row sums into per-row affine coefficients.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -503,6 +504,172 @@ inline int check_norm_args(int kind, int N, int C, int HW, int act) {
     return 0;
 }
 
+// ---- InstanceNorm2d fast paths: a row IS its statistics group, so statistics, coefficients and the apply pass need no
+// cross-row step and run in ONE launch per direction.  A row (<= 64 KB) is read from HBM once; the second / third sweep of
+// the same workgroup hits L1/L2.  TPR = 64: one wave per row (4 rows per workgroup); TPR = 256: one workgroup per row.
+constexpr int INST_FUSED_MAX_LEN = 16384;
+inline bool inst_fused_on() { static const bool on = !(getenv("SEMPYR_INST_FUSED") && getenv("SEMPYR_INST_FUSED")[0] == '0'); return on; }   // A/B aid
+
+template <int TPR>
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x, int rows, int C, int len, int vec,
+                                                           float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int act, float slope,
+                                                           float* __restrict__ y, float* __restrict__ rowbuf)
+{
+    __shared__ float sh[8];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const size_t base = (size_t)(live ? row : 0) * len;
+    const float* xr = x + base;
+    float s[1] = {0.f};
+    if (live) {
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xr);
+            for (int i = t; i < len / 4; i += TPR) { const float4 v = x4[i]; s[0] += (v.x + v.y) + (v.z + v.w); }
+        } else {
+            for (int i = t; i < len; i += TPR) s[0] += xr[i];
+        }
+    }
+    row_reduce<TPR, 1>(s, sh);
+    const float mean = s[0] / (float)len;
+    float q[1] = {0.f};
+    if (live) {
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xr);
+            for (int i = t; i < len / 4; i += TPR) {
+                const float4 v = x4[i];
+                const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+                q[0] += (a * a + b * b) + (c * c + d * d);
+            }
+        } else {
+            for (int i = t; i < len; i += TPR) { const float a = xr[i] - mean; q[0] += a * a; }
+        }
+    }
+    row_reduce<TPR, 1>(q, sh);
+    if (!live) return;
+    const float var = q[0] / (float)len;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const int c = row % C;
+    const float sc = rstd * gamma[c], sf = beta[c];
+    if (t == 0) { rowbuf[row] = mean; rowbuf[rows + row] = rstd; rowbuf[2 * rows + row] = sc; rowbuf[3 * rows + row] = sf; }
+    float* yr = y + base;
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(xr);
+        float4* y4 = reinterpret_cast<float4*>(yr);
+        for (int i = t; i < len / 4; i += TPR) {
+            const float4 v = x4[i];
+            float4 o;
+            o.x = act_apply((v.x - mean) * sc + sf, act, slope); o.y = act_apply((v.y - mean) * sc + sf, act, slope);
+            o.z = act_apply((v.z - mean) * sc + sf, act, slope); o.w = act_apply((v.w - mean) * sc + sf, act, slope);
+            y4[i] = o;
+        }
+    } else {
+        for (int i = t; i < len; i += TPR) yr[i] = act_apply((xr[i] - mean) * sc + sf, act, slope);
+    }
+}
+
+// backward: pivot-shifted row sums as norm_bwd_rowsums_kernel, the coefficient step of norm_bwd_finalize_kernel for a
+// one-row group (double math), then the apply sweep.  `sums` [4][rows] is still written: the channel kernel below turns it
+// into ggamma / gbeta.
+template <int TPR>
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                           const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+                                                           int rows, int C, int len, int vec, int act, float slope,
+                                                           float* __restrict__ gx, float* __restrict__ sums)
+{
+    __shared__ float sh[12];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const size_t base = (size_t)(live ? row : 0) * len;
+    const float mean = mean_row[live ? row : 0];
+    float Kg = gy[base];
+    if (act != SEMPYR_ACT_NONE) Kg *= act_deriv(y[base], act, slope);
+    float s[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        if (vec) {
+            const float4* g4 = reinterpret_cast<const float4*>(gy + base);
+            const float4* x4 = reinterpret_cast<const float4*>(x + base);
+            const float4* y4 = reinterpret_cast<const float4*>(y + base);
+            for (int i = t; i < len / 4; i += TPR) {
+                float4 g = g4[i]; float4 xv = x4[i];
+                if (act != SEMPYR_ACT_NONE) {
+                    const float4 yv = y4[i];
+                    g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
+                    g.z *= act_deriv(yv.z, act, slope); g.w *= act_deriv(yv.w, act, slope);
+                }
+                g.x -= Kg; g.y -= Kg; g.z -= Kg; g.w -= Kg;
+                xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
+                s[0] += (g.x + g.y) + (g.z + g.w);
+                s[1] += (xv.x + xv.y) + (xv.z + xv.w);
+                s[2] += (g.x * xv.x + g.y * xv.y) + (g.z * xv.z + g.w * xv.w);
+            }
+        } else {
+            for (int i = t; i < len; i += TPR) {
+                float g = gy[base + i];
+                if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[base + i], act, slope);
+                g -= Kg;
+                const float xc = x[base + i] - mean;
+                s[0] += g; s[1] += xc; s[2] += g * xc;
+            }
+        }
+    }
+    row_reduce<TPR, 3>(s, sh);
+    if (!live) return;
+    if (t == 0) { sums[row] = Kg; sums[rows + row] = s[0]; sums[2 * rows + row] = s[1]; sums[3 * rows + row] = s[2]; }
+    const double r = rstd_row[row], gm = gamma[row % C];
+    const double G1 = (double)Kg * len + (double)s[0];
+    const double G2 = ((double)s[2] + (double)Kg * (double)s[1]) * r;
+    const double m = (double)len;
+    const float a = (float)(r * gm), b = (float)(-r * r * (gm * G2 / m)), c = (float)(-r * (gm * G1 / m));
+    if (vec) {
+        const float4* g4 = reinterpret_cast<const float4*>(gy + base);
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        const float4* y4 = reinterpret_cast<const float4*>(y + base);
+        float4* o4 = reinterpret_cast<float4*>(gx + base);
+        for (int i = t; i < len / 4; i += TPR) {
+            float4 g = g4[i]; float4 xv = x4[i];
+            xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
+            if (act != SEMPYR_ACT_NONE) {
+                const float4 yv = y4[i];
+                g.x *= act_deriv(yv.x, act, slope); g.y *= act_deriv(yv.y, act, slope);
+                g.z *= act_deriv(yv.z, act, slope); g.w *= act_deriv(yv.w, act, slope);
+            }
+            float4 o;
+            o.x = a * g.x + b * xv.x + c; o.y = a * g.y + b * xv.y + c;
+            o.z = a * g.z + b * xv.z + c; o.w = a * g.w + b * xv.w + c;
+            o4[i] = o;
+        }
+    } else {
+        for (int i = t; i < len; i += TPR) {
+            float g = gy[base + i];
+            if (act != SEMPYR_ACT_NONE) g *= act_deriv(y[base + i], act, slope);
+            gx[base + i] = a * g + b * (x[base + i] - mean) + c;
+        }
+    }
+}
+
+// ggamma[c] = sum_n sum gy'*xhat, gbeta[c] = sum_n sum gy' from the shifted row sums (double math, as the finalize kernel)
+__global__ void norm_bwd_channel_kernel(const float* __restrict__ sums, const float* __restrict__ rstd_row, int N, int C,
+                                        int len, float* __restrict__ ggamma, float* __restrict__ gbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int rows = N * C;
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const int row = n * C + c;
+        a += (double)sums[row] * len + (double)sums[rows + row];
+        b += ((double)sums[3 * rows + row] + (double)sums[row] * (double)sums[2 * rows + row]) * (double)rstd_row[row];
+    }
+    if (gbeta) gbeta[c] = (float)a;
+    if (ggamma) ggamma[c] = (float)b;
+}
+
 } // namespace
 
 extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
@@ -525,6 +692,27 @@ extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW,
                        rowbuf, rowbuf + rows, rowbuf + 2 * rows, rowbuf + 3 * rows);
     SEMPYR_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sempyr_norm_fwd(int kind, const float* x, int N, int C, int HW, float eps,
+                               const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                               int act, float slope, float* y, float* rowbuf, float* scratch, void* stream)
+{
+    if (int rc = check_norm_args(kind, N, C, HW, act)) return rc;
+    if (!x || !gamma || !beta || !y || !rowbuf || !scratch) SEMPYR_FAIL("norm_fwd: null pointer");
+    const int rows = N * C;
+    if (kind == SEMPYR_NORM_INSTANCE && HW <= INST_FUSED_MAX_LEN && inst_fused_on()) {
+        hipStream_t st = (hipStream_t)stream;
+        const int vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+        if (HW >= 2048) hipLaunchKernelGGL(instnorm_fwd_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, C, HW, vec, eps, gamma, beta, act, slope, y, rowbuf);
+        else hipLaunchKernelGGL(instnorm_fwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, C, HW, vec, eps, gamma, beta, act, slope, y, rowbuf);
+        SEMPYR_CHECK_LAUNCH();
+        return 0;
+    }
+    if (int rc = sempyr_norm_stats(kind, x, N, C, HW, eps, gamma, beta, running_mean, running_var, num_batches_tracked,
+                                   momentum, rowbuf, scratch, stream)) return rc;
+    return sempyr_affine_act(x, rowbuf, rowbuf + 2 * rows, rowbuf + 3 * rows, nullptr, y, rows, HW, act, slope, stream);
 }
 
 extern "C" int sempyr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
@@ -551,6 +739,16 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     const int rows = N * C;
     const int vec = (HW % 4 == 0) && aligned16(gy) && aligned16(x) && aligned16(gx) && (act == SEMPYR_ACT_NONE || aligned16(y));
     float* sums = scratch;
+    if (kind == SEMPYR_NORM_INSTANCE && HW <= INST_FUSED_MAX_LEN && inst_fused_on()) {
+        if (HW >= 2048) hipLaunchKernelGGL(instnorm_bwd_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);
+        else hipLaunchKernelGGL(instnorm_bwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);
+        SEMPYR_CHECK_LAUNCH();
+        if (ggamma || gbeta) {
+            hipLaunchKernelGGL(norm_bwd_channel_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, sums, rstd_row, N, C, HW, ggamma, gbeta);
+            SEMPYR_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     float* cA = scratch + 4 * rows; float* cB = scratch + 5 * rows; float* cC = scratch + 6 * rows;
     if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);

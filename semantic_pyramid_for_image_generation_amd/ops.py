@@ -578,10 +578,20 @@ class _NormAct(Function):
         x = _req(x, "norm input"); gamma = _req(gamma, "norm weight"); beta = _req(beta, "norm bias")
         N, C, HW = _nchw(x)
         rows = N * C
-        rowbuf = _norm_stats(x, gamma, beta, kind, eps, bn_state)
+        rowbuf = torch.empty(4 * rows, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
+        rm = rv = nbt = None
+        momentum = 0.0
+        if bn_state is not None:
+            rm, rv, nbt, momentum = bn_state
         y = torch.empty_like(x)
-        check(L.sempyr_affine_act(x.data_ptr(), rowbuf.data_ptr(), rowbuf.data_ptr() + 8 * rows, rowbuf.data_ptr() + 12 * rows,
-                                  0, y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
+        # statistics + apply in one call (one launch for InstanceNorm rows up to 16384 elements)
+        check(L.sempyr_norm_fwd(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(), _p(rm), _p(rv), _p(nbt),
+                                momentum, act_kind, slope, y.data_ptr(), rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
+              "sempyr_norm_fwd")
+        if bn_state is not None:      # the kernel updated the buffers through raw pointers: tell version-keyed caches
+            torch.autograd.graph.increment_version(rm)
+            torch.autograd.graph.increment_version(rv)
         ctx.save_for_backward(x, y if act_kind != ACT_NONE else None, gamma, rowbuf)
         ctx.cfg = (kind, act_kind, slope)
         return y
