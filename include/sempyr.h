@@ -82,6 +82,19 @@ int sempyr_conv2d_tables(const sempyr_conv_desc* d, int mode, int32_t* ktab_host
 int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, const float* w,
                                const int32_t* wsrc_dev, float* wpacked, void* stream);
 
+/* sempyr_conv2d_pack_weights for many (descriptor, mode, weight) items in one launch: every packed layout of a module is
+ * refreshed right behind its optimizer step (train_model.py:117,143) instead of one small launch in front of each
+ * convolution of the next pass. `items` is a HOST array (SEMPYR_PACK_MAX_ITEMS per launch). */
+#define SEMPYR_PACK_MAX_ITEMS 64
+typedef struct sempyr_pack_item {
+    sempyr_conv_desc desc;
+    int32_t mode;
+    const float* w;
+    const int32_t* wsrc_dev;
+    float* wpacked;
+} sempyr_pack_item;
+int sempyr_conv2d_pack_weights_many(const sempyr_pack_item* items, int n_items, void* stream);
+
 /* y[B,Cout,Ho,Wo] = act(scale[Cout] * conv(x, w) + bias[Cout] + res[B,Cout,Ho,Wo]); scale, bias and res are each optional
  * (NULL = absent). scale + bias fold an eval-mode BatchNorm2d into the epilogue and res the identity branch of a ResNet
  * BasicBlock (the frozen classifier, classifier.py:34-40 under .eval(); the generator under eval_model.py). They are

@@ -34,6 +34,10 @@ class ConvPlanInfo(ctypes.Structure):
                 ("splits", ctypes.c_int32 * MAX_PHASES), ("cfg", ctypes.c_int32)]
 
 
+class PackItem(ctypes.Structure):
+    _fields_ = [("desc", ConvDesc), ("mode", ctypes.c_int32), ("w", c_void_p), ("wsrc", c_void_p), ("wpacked", c_void_p)]
+
+
 class AdamTensor(ctypes.Structure):
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
                 ("numel", ctypes.c_int64)]
@@ -51,6 +55,7 @@ SIGNATURES = {
     "sempyr_conv2d_plan": [_DESC, c_int, ctypes.POINTER(ConvPlanInfo)],
     "sempyr_conv2d_tables": [_DESC, c_int, _P, _P],
     "sempyr_conv2d_pack_weights": [_DESC, c_int, _P, _P, _P, _P],
+    "sempyr_conv2d_pack_weights_many": [ctypes.POINTER(PackItem), c_int, _P],
     "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, _P, c_size_t, _P],

@@ -1081,6 +1081,34 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     wp[i] = (s >= 0 && m < M) ? w[(size_t)s + (size_t)m * mstride] : 0.f;
 }
 
+// The same for many weight tensors in ONE launch (all packed layouts of a module, refreshed right behind its optimizer
+// step instead of one small launch in front of each convolution of the next pass).  The item table travels in the kernel
+// arguments; a workgroup finds its item by a binary search over the items' first-workgroup index.
+constexpr int PACK_MAX = SEMPYR_PACK_MAX_ITEMS;
+struct PackManyArgs {
+    const float* w[PACK_MAX];
+    const int* wsrc[PACK_MAX];
+    float* wp[PACK_MAX];
+    int first_block[PACK_MAX + 1];
+    int total[PACK_MAX], Mpad[PACK_MAX], M[PACK_MAX], mstride[PACK_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_weights_many_kernel(const PackManyArgs a)
+{
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int it = lo;
+    const int i = ((int)blockIdx.x - a.first_block[it]) * 256 + threadIdx.x;
+    if (i >= a.total[it]) return;
+    const int Mpad = a.Mpad[it];
+    const int k = i / Mpad, m = i - k * Mpad;
+    const int s = a.wsrc[it][k];
+    a.wp[it][i] = (s >= 0 && m < a.M[it]) ? a.w[it][(size_t)s + (size_t)m * a.mstride[it]] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1532,6 +1560,39 @@ extern "C" int sempyr_conv2d_pack_weights(const sempyr_conv_desc* d, int mode, c
                        w, wsrc_dev, wpacked, pl.tab_entries, pl.Mpad, M, mstride);
     SEMPYR_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sempyr_conv2d_pack_weights_many(const sempyr_pack_item* items, int n_items, void* stream)
+{
+    if (!items || n_items < 1) SEMPYR_FAIL("pack_weights_many: empty item list");
+    PackManyArgs a;
+    int n = 0; long long blocks = 0;
+    auto flush = [&]() -> int {
+        if (n == 0) return 0;
+        a.first_block[n] = (int)blocks; a.n = n;
+        hipLaunchKernelGGL(pack_weights_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        SEMPYR_CHECK_LAUNCH();
+        n = 0; blocks = 0;
+        return 0;
+    };
+    for (int i = 0; i < n_items; ++i) {
+        const sempyr_pack_item& it = items[i];
+        sempyr_conv_plan pl;
+        if (int rc = sempyr_conv2d_plan(&it.desc, it.mode, &pl)) return rc;
+        if (it.mode == SEMPYR_CONV_WGRAD) SEMPYR_FAIL("pack_weights_many: WGRAD has no packed weights");
+        if (!it.w || !it.wsrc_dev || !it.wpacked) SEMPYR_FAIL("pack_weights_many: item %d has a null pointer", i);
+        const int T = it.desc.kh * it.desc.kw;
+        const long long total = (long long)pl.tab_entries * pl.Mpad;
+        if (total == 0) continue;
+        if (total >= (1ll << 31)) SEMPYR_FAIL("pack_weights_many: item %d too large", i);
+        a.w[n] = it.w; a.wsrc[n] = it.wsrc_dev; a.wp[n] = it.wpacked;
+        a.first_block[n] = (int)blocks; a.total[n] = (int)total; a.Mpad[n] = pl.Mpad;
+        a.M[n] = it.mode == SEMPYR_CONV_FWD ? it.desc.Cout : it.desc.Cin;
+        a.mstride[n] = it.mode == SEMPYR_CONV_FWD ? it.desc.Cin * T : T;
+        blocks += (total + 255) / 256; ++n;
+        if (n == PACK_MAX || blocks > (1ll << 30)) { if (int rc = flush()) return rc; }
+    }
+    return flush();
 }
 
 static int run_splitk_reduce(const float* slabs, float* out, const float* bias, int splits, long long numel,

@@ -335,8 +335,56 @@ def _packed_weights(plan, w, mode):
         cur = torch.cuda.current_stream(w.device)
         ev = torch.cuda.Event()
         ev.record(cur)
-        cache[wkey] = (w._version, wp, w.data_ptr(), ev, cur.cuda_stream)
+        cache[wkey] = (w._version, wp, w.data_ptr(), ev, cur.cuda_stream, plan, mode)
     return wp
+
+
+_REPACK = os.environ.get("SEMPYR_REPACK", "1") != "0"
+
+
+def repack_cached(params, table_cache=None):
+    """Refresh every cached packed layout of `params` (tensors an optimizer has just updated in place) with ONE launch on
+    the current stream, into the buffers the cache already holds.  Without it the first convolution that touches a weight
+    after the step re-packs it with a launch of its own (~100 small launches per cycle at the head of each pass).
+    Must run stream-ordered after every reader of the old weights — which the in-place optimizer step requires anyway.
+    `table_cache`: a dict the caller keeps, so the ctypes item table is rebuilt only when the set of layouts changes."""
+    if not _REPACK:
+        return
+    entries = []
+    sig = []
+    for w in params:
+        cache = getattr(w, "_sempyr_pack", None)
+        if not cache:
+            continue
+        ptr = w.data_ptr()
+        for wkey, hit in cache.items():
+            if hit[2] == ptr:
+                entries.append((w, wkey, hit))
+                sig.append((ptr, hit[1].data_ptr(), hit[6]))
+    if not entries:
+        return
+    dev = entries[0][0].device
+    sig = tuple(sig)
+    arr = None
+    if table_cache is not None and table_cache.get("sig") == sig:
+        arr = table_cache["arr"]
+    if arr is None:
+        arr = (_lib.PackItem * len(entries))()
+        for i, (w, wkey, hit) in enumerate(entries):
+            plan, mode = hit[5], hit[6]
+            it = arr[i]
+            it.desc = plan.desc
+            it.mode = mode
+            it.w = w.data_ptr(); it.wsrc = plan.mode(mode).wsrc.data_ptr(); it.wpacked = hit[1].data_ptr()
+        if table_cache is not None:
+            table_cache["sig"] = sig; table_cache["arr"] = arr
+    raw = _raw_stream(dev.index)
+    check(L.sempyr_conv2d_pack_weights_many(arr, len(entries), raw), "sempyr_conv2d_pack_weights_many")
+    cur = _current_stream_obj(dev)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    for w, wkey, hit in entries:
+        w._sempyr_pack[wkey] = (w._version, hit[1], hit[2], ev, raw, hit[5], hit[6])
 
 
 def _workspace(nbytes, device):

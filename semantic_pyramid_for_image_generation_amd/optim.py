@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 L = _lib.lib
 
@@ -33,6 +33,7 @@ class Adam(torch.optim.Optimizer):
         self.grad_scale = float(grad_scale)
         self.zero_grads = bool(zero_grads)
         self._tables = {}
+        self._pack_tables = {}
 
     def _table(self, key, entries):
         """ctypes tensor table for one (group, step) cohort; param / state pointers are stable, gradients are re-read."""
@@ -95,4 +96,6 @@ class Adam(torch.optim.Optimizer):
                 # the kernel wrote through raw pointers: bump the autograd version counters (packed-weight and
                 # eval-BatchNorm caches are keyed on them)
                 torch.autograd.graph.increment_version([e[0] for e in entries])
+            # the convolutions read weights through packed copies: refresh all of them with one launch
+            ops.repack_cached(group['params'], self._pack_tables.setdefault(gi, {}))
         return loss

@@ -95,3 +95,29 @@ def test_adam_interface_matches_torch():
     from semantic_pyramid_for_image_generation_amd._lib import SempyrError
     with pytest.raises(SempyrError):
         a.step()
+
+
+@pytest.mark.gpu
+def test_adam_step_refreshes_packed_weights(dev):
+    """The optimizer step re-packs every cached k-major weight copy in one launch: the next convolution finds a valid cache
+    entry (no pack launch of its own) and computes with the UPDATED weights."""
+    import torch.nn.functional as F
+    from semantic_pyramid_for_image_generation_amd import ops, optim
+    gen = torch.Generator().manual_seed(7)
+    w1 = torch.nn.Parameter((torch.randn(16, 8, 3, 3, generator=gen) * 0.1).to(dev))
+    w2 = torch.nn.Parameter((torch.randn(8, 16, 4, 4, generator=gen) * 0.1).to(dev))
+    x = torch.randn(2, 8, 12, 12, generator=gen).to(dev)
+    opt = optim.Adam([w1, w2], lr=1e-2, betas=(0.5, 0.999))
+    for _ in range(2):
+        y = ops.conv2d(ops.conv2d(x, w1, None, 1, 1), w2, None, 2, 1)
+        opt.zero_grad()
+        y.square().mean().backward()          # forward + input-gradient layouts of both weights are now cached
+        opt.step()
+        for w in (w1, w2):
+            assert len(w._sempyr_pack) >= 1
+            for hit in w._sempyr_pack.values():
+                assert hit[0] == w._version
+    with torch.no_grad():
+        got = ops.conv2d(ops.conv2d(x, w1, None, 1, 1), w2, None, 2, 1)
+        want = F.conv2d(F.conv2d(x.cpu(), w1.detach().cpu(), None, 1, 1), w2.detach().cpu(), None, 2, 1)
+    assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
