@@ -206,6 +206,53 @@ __global__ __launch_bounds__(256) void pool2_up_kernel(const float* __restrict__
     *(p0 + w) = b;
 }
 
+// Two coarse pixels per thread (w even, 16-byte aligned tensors): every fine-resolution access is a float4
+__global__ __launch_bounds__(256) void pool2_up_v2_kernel(const float* __restrict__ x, const float* __restrict__ yref,
+                                                          float* __restrict__ y, long long total_pairs, int h, int w2,
+                                                          float scale, int act, float slope)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_pairs) return;
+    const int ix = (int)(i % w2);                       // pair index inside the coarse row
+    const long long t = i / w2;                         // coarse row index (r * h + iy)
+    const float2 xv = reinterpret_cast<const float2*>(x)[i];
+    const float v0 = scale * xv.x, v1 = scale * xv.y;
+    const long long off = t * (8 * (long long)w2) + 4 * ix;      // fine row 2*iy of plane r: (t * 2) * (4 * w2)
+    float4 a = make_float4(v0, v0, v1, v1), b = a;
+    if (yref) {
+        const float4 ya = *reinterpret_cast<const float4*>(yref + off);
+        const float4 yb = *reinterpret_cast<const float4*>(yref + off + 4 * w2);
+        a.x *= act_deriv_y(ya.x, act, slope); a.y *= act_deriv_y(ya.y, act, slope);
+        a.z *= act_deriv_y(ya.z, act, slope); a.w *= act_deriv_y(ya.w, act, slope);
+        b.x *= act_deriv_y(yb.x, act, slope); b.y *= act_deriv_y(yb.y, act, slope);
+        b.z *= act_deriv_y(yb.z, act, slope); b.w *= act_deriv_y(yb.w, act, slope);
+    }
+    *reinterpret_cast<float4*>(y + off) = a;
+    *reinterpret_cast<float4*>(y + off + 4 * w2) = b;
+}
+
+__global__ __launch_bounds__(256) void pool2_down_v2_kernel(const float* __restrict__ x, const float* __restrict__ yref,
+                                                            float* __restrict__ y, long long total_pairs, int h, int w2,
+                                                            float scale, int act, float slope)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_pairs) return;
+    const int ox = (int)(i % w2);
+    const long long t = i / w2;
+    const long long off = t * (8 * (long long)w2) + 4 * ox;
+    float4 a = *reinterpret_cast<const float4*>(x + off);
+    float4 b = *reinterpret_cast<const float4*>(x + off + 4 * w2);
+    if (yref) {
+        const float4 ya = *reinterpret_cast<const float4*>(yref + off);
+        const float4 yb = *reinterpret_cast<const float4*>(yref + off + 4 * w2);
+        a.x *= act_deriv_y(ya.x, act, slope); a.y *= act_deriv_y(ya.y, act, slope);
+        a.z *= act_deriv_y(ya.z, act, slope); a.w *= act_deriv_y(ya.w, act, slope);
+        b.x *= act_deriv_y(yb.x, act, slope); b.y *= act_deriv_y(yb.y, act, slope);
+        b.z *= act_deriv_y(yb.z, act, slope); b.w *= act_deriv_y(yb.w, act, slope);
+    }
+    reinterpret_cast<float2*>(y)[i] = make_float2(scale * ((a.x + a.y) + (b.x + b.y)), scale * ((a.z + a.w) + (b.z + b.w)));
+}
+
 // 3x3 stride-2 pad-1 max pool; idx = flat offset (iy*W+ix) of the first maximum in scan order
 __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int* __restrict__ idx, long long total_out,
@@ -352,6 +399,10 @@ extern "C" int sempyr_pool2_down(const float* x, const float* yref, float* y, in
     if ((((uintptr_t)x | (uintptr_t)yref) & 7) != 0) SEMPYR_FAIL("pool2_down: inputs must be 8-byte aligned");
     if (act < 0 || act > 3) SEMPYR_FAIL("pool2_down: bad activation %d", act);
     const long long total = (long long)rows * (H / 2) * (W / 2);
+    if ((W & 3) == 0 && ((((uintptr_t)x | (uintptr_t)yref) & 15) == 0) && (((uintptr_t)y & 7) == 0)) {
+        LAUNCH_1D(pool2_down_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, H / 2, W / 4, scale, act, slope);
+        return 0;
+    }
     LAUNCH_1D(pool2_down_kernel, total, (hipStream_t)stream, x, yref, y, total, H / 2, W / 2, scale, act, slope);
     return 0;
 }
@@ -363,6 +414,10 @@ extern "C" int sempyr_pool2_up(const float* x, const float* yref, float* y, int 
     if ((((uintptr_t)y | (uintptr_t)yref) & 7) != 0) SEMPYR_FAIL("pool2_up: output / yref must be 8-byte aligned");
     if (act < 0 || act > 3) SEMPYR_FAIL("pool2_up: bad activation %d", act);
     const long long total = (long long)rows * h * w;
+    if ((w & 1) == 0 && ((((uintptr_t)y | (uintptr_t)yref) & 15) == 0) && (((uintptr_t)x & 7) == 0)) {
+        LAUNCH_1D(pool2_up_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, h, w / 2, scale, act, slope);
+        return 0;
+    }
     LAUNCH_1D(pool2_up_kernel, total, (hipStream_t)stream, x, yref, y, total, h, w, scale, act, slope);
     return 0;
 }
