@@ -213,9 +213,11 @@ int sempyr_pool2_down(const float* x, const float* yref, float* y, int rows, int
                       int act, float slope, void* stream);
 /* y[r][2h+a][2w+b] = scale*x[r][h][w] : nn.UpsamplingNearest2d(2) generator.py:44 ; avg-pool backward (scale .25).
  * yref (optional, fine resolution): the result is multiplied by act'(yref) -- the backward of
- * `LeakyReLU -> AvgPool2d` (discriminator.py:107-109) in one pass. */
+ * `LeakyReLU -> AvgPool2d` (discriminator.py:107-109) in one pass. row_partials (optional, [rows][h*w/512] floats, needs
+ * h*w % 512 == 0): partial sums of y per row, so the bias gradient of the conv in front (a channel sum of y) needs no second
+ * pass over the full-resolution tensor. */
 int sempyr_pool2_up(const float* x, const float* yref, float* y, int rows, int h, int w, float scale,
-                    int act, float slope, void* stream);
+                    int act, float slope, float* row_partials, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the ResNet18 stem classifier.py:36 ; idx = argmax offsets for the backward */
 int sempyr_maxpool3s2_fwd(const float* x, float* y, int32_t* idx, int rows, int H, int W, void* stream);
 int sempyr_maxpool3s2_bwd(const float* gy, const int32_t* idx, float* gx, int rows, int H, int W, void* stream);

@@ -74,7 +74,7 @@ SIGNATURES = {
     "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],
     "sempyr_normalize": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "sempyr_pool2_down": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
-    "sempyr_pool2_up": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
+    "sempyr_pool2_up": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P],
     "sempyr_maxpool3s2_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "sempyr_maxpool3s2_bwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "sempyr_reduce_scratch_floats": [],

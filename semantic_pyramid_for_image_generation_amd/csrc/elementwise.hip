@@ -207,12 +207,15 @@ __global__ __launch_bounds__(256) void pool2_up_kernel(const float* __restrict__
 }
 
 // Two coarse pixels per thread (w even, 16-byte aligned tensors): every fine-resolution access is a float4
+// `partials` (optional): sum of the workgroup's outputs, one float per workgroup (= [row][h*w/512] when a plane is a whole
+// number of workgroups) -- the per-row sums of the result (a conv bias gradient) without reading it back.
 __global__ __launch_bounds__(256) void pool2_up_v2_kernel(const float* __restrict__ x, const float* __restrict__ yref,
                                                           float* __restrict__ y, long long total_pairs, int h, int w2,
-                                                          float scale, int act, float slope)
+                                                          float scale, int act, float slope, float* __restrict__ partials)
 {
+    __shared__ float sh[4];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total_pairs) return;
+    if (i >= total_pairs) return;                       // (never taken with partials: the host checks total_pairs % 256 == 0)
     const int ix = (int)(i % w2);                       // pair index inside the coarse row
     const long long t = i / w2;                         // coarse row index (r * h + iy)
     const float2 xv = reinterpret_cast<const float2*>(x)[i];
@@ -229,6 +232,10 @@ __global__ __launch_bounds__(256) void pool2_up_v2_kernel(const float* __restric
     }
     *reinterpret_cast<float4*>(y + off) = a;
     *reinterpret_cast<float4*>(y + off + 4 * w2) = b;
+    if (partials) {
+        const float s = block_sum_256(((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)), sh);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void pool2_down_v2_kernel(const float* __restrict__ x, const float* __restrict__ yref,
@@ -408,16 +415,18 @@ extern "C" int sempyr_pool2_down(const float* x, const float* yref, float* y, in
 }
 
 extern "C" int sempyr_pool2_up(const float* x, const float* yref, float* y, int rows, int h, int w, float scale,
-                               int act, float slope, void* stream)
+                               int act, float slope, float* row_partials, void* stream)
 {
     if (!x || !y || rows < 1 || h < 1 || w < 1) SEMPYR_FAIL("pool2_up: bad arguments");
     if ((((uintptr_t)y | (uintptr_t)yref) & 7) != 0) SEMPYR_FAIL("pool2_up: output / yref must be 8-byte aligned");
     if (act < 0 || act > 3) SEMPYR_FAIL("pool2_up: bad activation %d", act);
     const long long total = (long long)rows * h * w;
     if ((w & 1) == 0 && ((((uintptr_t)y | (uintptr_t)yref) & 15) == 0) && (((uintptr_t)x & 7) == 0)) {
-        LAUNCH_1D(pool2_up_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, h, w / 2, scale, act, slope);
+        if (row_partials && ((long long)h * w) % 512 != 0) SEMPYR_FAIL("pool2_up: row partials need h*w to be a multiple of 512");
+        LAUNCH_1D(pool2_up_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, h, w / 2, scale, act, slope, row_partials);
         return 0;
     }
+    if (row_partials) SEMPYR_FAIL("pool2_up: row partials need an even width and 16-byte aligned tensors");
     LAUNCH_1D(pool2_up_kernel, total, (hipStream_t)stream, x, yref, y, total, h, w, scale, act, slope);
     return 0;
 }

@@ -207,7 +207,7 @@ def _current_stream_obj(device):
     return st
 
 
-def _param_grads_async(gy, x, plan, w, bias, want_w, want_b):
+def _param_grads_async(gy, x, plan, w, bias, want_w, want_b, bsrc=None):
     """WGRAD(gy, x) -> w.grad and channel_sum(gy) -> bias.grad on the side stream."""
     dev = gy.device
     main = _current_stream_obj(dev)
@@ -224,11 +224,14 @@ def _param_grads_async(gy, x, plan, w, bias, want_w, want_b):
             else:
                 _accumulate_grad(w, _raw_conv_wgrad(plan, gy, x), main)
         if want_b:
+            src = gy if bsrc is None else bsrc
             cur = _grad_in_place(bias)
             if cur is not None:
-                _channel_sum_raw(gy, into=cur)
+                _channel_sum_raw(src, into=cur)
             else:
-                _accumulate_grad(bias, _channel_sum_raw(gy), main)
+                _accumulate_grad(bias, _channel_sum_raw(src), main)
+            if bsrc is not None:
+                bsrc.record_stream(side)
     finally:
         torch.cuda.set_stream(main)
     gy.record_stream(side)
@@ -471,21 +474,29 @@ class _ConvFwd(Function):
         x, w, y, bias = ctx.saved_tensors
         plan = ctx.plan
         gy = gy.contiguous()
+        want_w = ctx.needs_input_grad[1] and not _INPUT_GRADS_ONLY
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not _INPUT_GRADS_ONLY
+        bsrc = None               # what the bias gradient is the channel sum of (default: gy itself)
         if ctx.pool:
-            gy = _apply(_Pool2Up, gy, 0.25, y, *ctx.act)
+            h, wd = gy.shape[2], gy.shape[3]
+            if want_b and not torch.is_grad_enabled() and (h * wd) % 512 == 0 and wd % 2 == 0 and y.data_ptr() % 16 == 0:
+                # the un-pool pass also emits per-row partial sums: the bias gradient needs no second pass over the
+                # full-resolution gradient
+                bsrc = torch.empty((gy.shape[0], gy.shape[1], (h * wd) // 512), dtype=torch.float32, device=gy.device)
+                gy = _pool2_up_raw(_req(gy, "grad"), 0.25, y, *ctx.act, partials=bsrc)
+            else:
+                gy = _apply(_Pool2Up, gy, 0.25, y, *ctx.act)
         elif y is not None:
             gy = _apply(_ActBwd, gy, y, *ctx.act)
         gx = gw = gb = None
-        if not _INPUT_GRADS_ONLY:
-            want_w = ctx.needs_input_grad[1]
-            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w or want_b:
             if _can_async(w, bias, want_w, want_b):
-                _param_grads_async(gy, x, plan, w, bias, want_w, want_b)     # issued first: overlaps the input gradient
+                _param_grads_async(gy, x, plan, w, bias, want_w, want_b, bsrc)     # issued first: overlaps the input gradient
             else:
                 if want_w:
                     gw = _apply(_ConvWgrad, gy, x, plan)
                 if want_b:
-                    gb = _bias_grad(gy)
+                    gb = _bias_grad(gy if bsrc is None else bsrc)
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(gy, w, plan)
         return gx, gw, gb, None, None, None, None
@@ -1019,16 +1030,21 @@ class _Pool2Down(Function):
         return _apply(_Pool2Up, g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
 
 
+def _pool2_up_raw(x, scale, yref=None, act_kind=ACT_NONE, slope=0.0, partials=None):
+    """`partials` ([N*C, h*w/512] floats): also receive per-row partial sums of the result (see sempyr_pool2_up)."""
+    N, C, h, w = x.shape
+    y = torch.empty((N, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    check(L.sempyr_pool2_up(x.data_ptr(), _p(yref), y.data_ptr(), N * C, h, w, scale, act_kind, slope, _p(partials),
+                            _stream()), "sempyr_pool2_up")
+    return y
+
+
 class _Pool2Up(Function):
     """y = scale * nearest_up2(x) * act'(yref); yref = None: plain nearest upsample."""
 
     @staticmethod
     def forward(ctx, x, scale, yref=None, act_kind=ACT_NONE, slope=0.0):
-        x = _req(x, "input")
-        N, C, h, w = x.shape
-        y = torch.empty((N, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-        check(L.sempyr_pool2_up(x.data_ptr(), _p(yref), y.data_ptr(), N * C, h, w, scale, act_kind, slope, _stream()),
-              "sempyr_pool2_up")
+        y = _pool2_up_raw(_req(x, "input"), scale, yref, act_kind, slope)
         ctx.save_for_backward(yref)
         ctx.cfg = (scale, act_kind, slope)
         return y
