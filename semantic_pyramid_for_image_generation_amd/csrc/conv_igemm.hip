@@ -1117,7 +1117,18 @@ enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3, CFG_64x19
 // Tile shape for a GATHER launch over N pixels (all stride phases of a DGRAD together).  `kind`: the kernel the launch
 // will run on — the choices below are measured (tools/bench_conv.py mid / small with SEMPYR_FORCE_CFG*).
 enum { KIND_GENERIC_FWD = 0, KIND_PATCH3X3 = 1, KIND_DGRAD = 2, KIND_ANY = 3 };
+inline int env_int(const char* name, int dflt);
 inline int pick_cfg(int Mpad, long long N = 1ll << 40, int kind = KIND_ANY) {
+    static const int small_tiles = env_int("SEMPYR_SMALL_TILES", 1);          // 0: the pre-tuning rules (A/B aid)
+    if (!small_tiles) {
+        if (Mpad % 128 == 0) return CFG_128x128;
+        if (Mpad % 64 == 0) {
+            if (kind == KIND_DGRAD || (kind == KIND_PATCH3X3 && N == (1ll << 40))) return CFG_64x256;
+            const long long t256 = (Mpad / 64) * ((N + 255) / 256), t64 = (Mpad / 64) * ((N + 63) / 64);
+            return (t256 < 512 && t64 >= 512) ? CFG_64x64 : CFG_64x256;
+        }
+        return CFG_32x256;
+    }
     if (Mpad % 128 == 0) {
         // few 128x128 tiles mean deep split-K (slab writes + a combine pass per launch): 64x64 tiles need a quarter of the
         // splits. Measured at batch 16: 3x3 128->128 @32^2 0.060 -> 0.048 ms, 512->512 @8^2 0.062 -> 0.051, input gradient
@@ -1486,7 +1497,8 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         // mid-size reductions (<= 2^17 pixels: the critic's blocks, the deep generator / classifier layers): 64x128 tiles
         // double the tile count, i.e. halve the split-K depth and the slabs the combine pass reads (measured 4-10 % on
         // the critic's 64->64 and 64->128 4x4 blocks, neutral elsewhere)
-        if ((plan->cfg == CFG_128x128 || plan->cfg == CFG_64x256) && plan->K[0] <= (1 << 17) && Nn % 128 == 0)
+        static const int w128 = env_int("SEMPYR_WGRAD_64x128", 1);
+        if (w128 && (plan->cfg == CFG_128x128 || plan->cfg == CFG_64x256) && plan->K[0] <= (1 << 17) && Nn % 128 == 0)
             plan->cfg = CFG_64x128;
         { static const int f = env_int("SEMPYR_FORCE_CFG_WGRAD", -1); if (f >= 0 && f != CFG_64x192 && plan->Mpad % (f == CFG_128x128 ? 128 : f == CFG_32x256 ? 32 : 64) == 0) plan->cfg = f; }
         cfg_dims(plan->cfg, bm, bn);
