@@ -133,11 +133,13 @@ int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, const float*
 enum { SEMPYR_NORM_BATCH = 0, SEMPYR_NORM_INSTANCE = 1, SEMPYR_NORM_LAYER = 2 };
 enum { SEMPYR_ACT_NONE = 0, SEMPYR_ACT_RELU = 1, SEMPYR_ACT_LRELU = 2, SEMPYR_ACT_TANH = 3 };
 
-/* scratch: 2*N*C floats. running_mean/var/num_batches_tracked (BATCH only) may be NULL. */
+/* scratch: 2*N*C floats. running_mean/var/num_batches_tracked (BATCH only) may be NULL. rep >= 1: x stands for a tensor in
+ * which every element occurs rep times (rep = 4: the nearest-x2-upsampled map of generator.py:44,60-62 whose 1x1 skip
+ * convolution was taken before the upsample) -- only the unbiased running_var depends on it. */
 int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
                       const float* gamma, const float* beta,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                      float* rowbuf, float* scratch, void* stream);
+                      int rep, float* rowbuf, float* scratch, void* stream);
 
 /* sempyr_norm_stats + the apply pass y = act((x - mean)*rstd*gamma + beta) as one call; InstanceNorm2d rows of up to 16384
  * elements (every critic layer, discriminator.py:16-26) run as ONE launch that reads x from HBM once. scratch: 2*N*C floats. */
@@ -175,10 +177,12 @@ int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, const float* 
 int sempyr_affine_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
                       const float* res, float* y, int rows, int len, int act, float slope, void* stream);
 /* y = act((x-sub)*scale+shift + (res-rsub)*rscale+rshift): two normalised branches summed and activated in one pass
- * (generator residual block: BatchNorm(conv2) + BatchNorm(skip) -> ReLU, generator.py:54-57). */
+ * (generator residual block: BatchNorm(conv2) + BatchNorm(skip) -> ReLU, generator.py:54-57). res_half_w > 0 (= the width
+ * of a row of x): res has half the resolution of x and is read through a nearest x2 upsample -- the 1x1 skip convolution
+ * of an upsampling block (generator.py:44,60-62) commutes with the upsample, so it runs on the low-resolution map. */
 int sempyr_affine2_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
                        const float* res, const float* rsub_row, const float* rscale_row, const float* rshift_row,
-                       float* y, int rows, int len, int act, float slope, void* stream);
+                       float* y, int rows, int len, int act, float slope, int res_half_w, void* stream);
 /* g' = gy*act'(y); gx = g'*scale_row (NULL -> 1), gres = g' ; either output may be NULL. */
 int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_row, float* gx, float* gres,
                           int rows, int len, int act, float slope, void* stream);

@@ -59,13 +59,13 @@ SIGNATURES = {
     "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, _P, c_size_t, _P],
-    "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, _P, _P, _P],
+    "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P],
     "sempyr_norm_fwd": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, c_float, _P, _P, _P, _P],
     "sempyr_bn_eval_coeffs": [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P],
     "sempyr_norm_bwd": [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
     "sempyr_norm_bwd_bwd": [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],
     "sempyr_affine_act": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
-    "sempyr_affine2_act": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
+    "sempyr_affine2_act": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P],
     "sempyr_affine_act_bwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
     "sempyr_mul": [_P, _P, _P, c_int64, _P],
     "sempyr_axpby": [_P, _P, c_float, c_float, _P, c_int64, _P],

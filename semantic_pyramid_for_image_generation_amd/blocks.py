@@ -104,13 +104,22 @@ def _train_norm_kind(layer):
     return None
 
 
-def run_norm_add_norm_act(norm_a, a, norm_b, b, act_kind=ops.ACT_NONE, slope=0.0):
+def tail_takes_half_res(norm_a, norm_b):
+    """True when run_norm_add_norm_act(..., b_half=True) is available: two training-mode BatchNorms."""
+    ka, kb = _train_norm_kind(norm_a), _train_norm_kind(norm_b)
+    return ka is not None and kb is not None and ka[0] == kb[0] == ops.NORM_BATCH
+
+
+def run_norm_add_norm_act(norm_a, a, norm_b, b, act_kind=ops.ACT_NONE, slope=0.0, b_half=False):
     """act(norm_a(a) + norm_b(b)) — the tail of a residual block.  Two training-mode norms of the same kind run as one
-    fused apply pass; anything else falls back to norm_b, then norm_a with the residual."""
+    fused apply pass; anything else falls back to norm_b, then norm_a with the residual.  `b_half`: b is the skip branch
+    taken BEFORE the block's nearest x2 upsample (see ops.norm_add_norm_act; check tail_takes_half_res first)."""
     ka, kb = _train_norm_kind(norm_a), _train_norm_kind(norm_b)
     if ka is not None and kb is not None and ka[0] == kb[0]:
         return ops.norm_add_norm_act(a, norm_a.weight, norm_a.bias, b, norm_b.weight, norm_b.bias, ka[0], act_kind, slope,
-                                     norm_a.eps, norm_b.eps, ka[1], kb[1])
+                                     norm_a.eps, norm_b.eps, ka[1], kb[1], b_half=b_half)
+    if b_half:
+        raise NotImplementedError("a half-resolution skip branch needs two training-mode BatchNorm layers")
     return run_norm(norm_a, a, act_kind, slope, res=run_norm(norm_b, b))
 
 

@@ -19,8 +19,11 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
                                                          const float* __restrict__ rsub, const float* __restrict__ rscale,
                                                          const float* __restrict__ rshift,
                                                          float* __restrict__ y, long long total, int len, int vec,
-                                                         int act, float slope)
+                                                         int act, float slope, int res_w)
 {
+    // res_w > 0: `res` has HALF the resolution (rows of res_w/2 pixels, len/4 per plane) and is read through a nearest x2
+    // upsample -- a 1x1 convolution commutes with nearest upsampling, so the skip branch of an upsampling residual block
+    // is computed (and normalised) at the low resolution and only expanded here.
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (vec) {
         if (i * 4 >= total) return;
@@ -30,7 +33,15 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
         float4 v = reinterpret_cast<const float4*>(x)[i];
         v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh; v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
         if (res) {
-            float4 r = reinterpret_cast<const float4*>(res)[i];
+            float4 r;
+            if (res_w > 0) {
+                const int rem = (int)(i * 4 - (long long)row * len);
+                const int yy = rem / res_w, xx = rem - yy * res_w;
+                const float2 lo = *reinterpret_cast<const float2*>(res + (size_t)row * (len >> 2) + (yy >> 1) * (res_w >> 1) + (xx >> 1));
+                r = make_float4(lo.x, lo.x, lo.y, lo.y);
+            } else {
+                r = reinterpret_cast<const float4*>(res)[i];
+            }
             if (rscale) {
                 const float rs = rscale[row], rh = rshift[row], rm = rsub ? rsub[row] : 0.f;
                 r.x = (r.x - rm) * rs + rh; r.y = (r.y - rm) * rs + rh; r.z = (r.z - rm) * rs + rh; r.w = (r.w - rm) * rs + rh;
@@ -46,7 +57,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
         float v = x[i];
         if (scale) v = (v - (sub ? sub[row] : 0.f)) * scale[row] + shift[row];
         if (res) {
-            float r = res[i];
+            float r;
+            if (res_w > 0) {
+                const int rem = (int)(i - (long long)row * len);
+                const int yy = rem / res_w, xx = rem - yy * res_w;
+                r = res[(size_t)row * (len >> 2) + (yy >> 1) * (res_w >> 1) + (xx >> 1)];
+            } else {
+                r = res[i];
+            }
             if (rscale) r = (r - (rsub ? rsub[row] : 0.f)) * rscale[row] + rshift[row];
             v += r;
         }
@@ -320,9 +338,11 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __rest
 
 static int affine_act_launch(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
                              const float* res, const float* rsub_row, const float* rscale_row, const float* rshift_row,
-                             float* y, int rows, int len, int act, float slope, void* stream)
+                             float* y, int rows, int len, int act, float slope, void* stream, int res_w = 0)
 {
     if (!x || !y) SEMPYR_FAIL("affine_act: null pointer");
+    if (res_w < 0 || (res_w > 0 && (!res || (res_w & 1) || len % res_w != 0 || ((len / res_w) & 1))))
+        SEMPYR_FAIL("affine_act: a half-resolution residual needs even height and width (len %d, width %d)", len, res_w);
     if ((scale_row == nullptr) != (shift_row == nullptr)) SEMPYR_FAIL("affine_act: scale and shift must both be given");
     if (sub_row && !scale_row) SEMPYR_FAIL("affine_act: sub_row needs scale/shift");
     if ((rscale_row == nullptr) != (rshift_row == nullptr)) SEMPYR_FAIL("affine_act: residual scale and shift must both be given");
@@ -330,9 +350,10 @@ static int affine_act_launch(const float* x, const float* sub_row, const float* 
     if (rows < 1 || len < 1) SEMPYR_FAIL("affine_act: bad dims");
     if (act < 0 || act > 3) SEMPYR_FAIL("affine_act: bad activation %d", act);
     const long long total = (long long)rows * len;
-    const int vec = (len % 4 == 0) && aligned16(x) && aligned16(y) && (!res || aligned16(res));
+    const int vec = (len % 4 == 0) && aligned16(x) && aligned16(y) &&
+                    (!res || (res_w > 0 ? (res_w % 4 == 0 && (((uintptr_t)res) & 7) == 0) : aligned16(res)));
     LAUNCH_1D(affine_act_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, sub_row, scale_row, shift_row, res,
-              rsub_row, rscale_row, rshift_row, y, total, len, vec, act, slope);
+              rsub_row, rscale_row, rshift_row, y, total, len, vec, act, slope, res_w);
     return 0;
 }
 
@@ -344,10 +365,11 @@ extern "C" int sempyr_affine_act(const float* x, const float* sub_row, const flo
 
 extern "C" int sempyr_affine2_act(const float* x, const float* sub_row, const float* scale_row, const float* shift_row,
                                   const float* res, const float* rsub_row, const float* rscale_row, const float* rshift_row,
-                                  float* y, int rows, int len, int act, float slope, void* stream)
+                                  float* y, int rows, int len, int act, float slope, int res_half_w, void* stream)
 {
     if (!res || !rscale_row) SEMPYR_FAIL("affine2_act: the residual and its coefficients are required");
-    return affine_act_launch(x, sub_row, scale_row, shift_row, res, rsub_row, rscale_row, rshift_row, y, rows, len, act, slope, stream);
+    return affine_act_launch(x, sub_row, scale_row, shift_row, res, rsub_row, rscale_row, rshift_row, y, rows, len, act, slope,
+                             stream, res_half_w);
 }
 
 extern "C" int sempyr_affine_act_bwd(const float* gy, const float* y, const float* scale_row, float* gx, float* gres,

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(int kind, const floa
                                      const float* __restrict__ row_m2,
                                      int N, int C, int len, float eps,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     float* running_mean, float* running_var, long long* nbt, float momentum,
+                                     float* running_mean, float* running_var, long long* nbt, float momentum, float rep,
                                      float* __restrict__ mean_row, float* __restrict__ rstd_row,
                                      float* __restrict__ scale_row, float* __restrict__ shift_row)
 {
@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(int kind, const floa
         scale_row[row] = sc; shift_row[row] = beta[c];     // y = (x - mean_row) * scale_row + shift_row
     }
     if (l == 0 && kind == SEMPYR_NORM_BATCH && running_mean) {
-        const float unbiased = m > 1.f ? m2 / (m - 1.f) : var;
+        // rep > 1: the tensor stands for one in which every element occurs `rep` times (a nearest-upsampled map): mean and
+        // biased variance are unchanged, the unbiased estimate counts rep * m elements
+        const float unbiased = m * rep > 1.f ? (m2 * rep) / (m * rep - 1.f) : var;
         running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * mean;
         running_var[g] = (1.f - momentum) * running_var[g] + momentum * unbiased;
         if (g == 0 && nbt) *nbt += 1;
@@ -675,10 +677,11 @@ __global__ void norm_bwd_channel_kernel(const float* __restrict__ sums, const fl
 extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
                                  const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                                 float* rowbuf, float* scratch, void* stream)
+                                 int rep, float* rowbuf, float* scratch, void* stream)
 {
     if (int rc = check_norm_args(kind, N, C, HW, 0)) return rc;
     if (!x || !gamma || !beta || !rowbuf || !scratch) SEMPYR_FAIL("norm_stats: null pointer");
+    if (rep < 1) SEMPYR_FAIL("norm_stats: replication factor %d", rep);
     hipStream_t st = (hipStream_t)stream;
     const int rows = N * C;
     const int vec = (HW % 4 == 0) && aligned16(x);
@@ -688,7 +691,7 @@ extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW,
     SEMPYR_CHECK_LAUNCH();
     const int ng = num_groups(kind, N, C);
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div((long long)ng * FIN_LPG, 256)), dim3(256), 0, st, kind, rmean, rm2, N, C, HW, eps,
-                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum,
+                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, (float)rep,
                        rowbuf, rowbuf + rows, rowbuf + 2 * rows, rowbuf + 3 * rows);
     SEMPYR_CHECK_LAUNCH();
     return 0;
@@ -711,7 +714,7 @@ extern "C" int sempyr_norm_fwd(int kind, const float* x, int N, int C, int HW, f
         return 0;
     }
     if (int rc = sempyr_norm_stats(kind, x, N, C, HW, eps, gamma, beta, running_mean, running_var, num_batches_tracked,
-                                   momentum, rowbuf, scratch, stream)) return rc;
+                                   momentum, 1, rowbuf, scratch, stream)) return rc;
     return sempyr_affine_act(x, rowbuf, rowbuf + 2 * rows, rowbuf + 3 * rows, nullptr, y, rows, HW, act, slope, stream);
 }
 

@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from . import ops
 from .blocks import (init_weights, run_conv, run_conv_norm, run_conv_norm_act,  # noqa: F401  (init_weights re-exported)
-                     run_norm_add_norm_act)
+                     run_norm_add_norm_act, tail_takes_half_res, _single)
 
 
 class ConvBlock(nn.Module):
@@ -46,11 +46,18 @@ class ResidualBlock(nn.Module):
             residual = run_conv_norm(self.skip_block.block[0], self.skip_block.block[1], x, upsample=up)
             h = self.conv_block1(x, upsample=up)
             return run_conv_norm(self.conv_block2.block[0], self.conv_block2.block[1], h, ops.ACT_RELU, res=residual)
-        residual = run_conv(self.skip_block.block[0], x, upsample=up)
+        # the 1x1 skip convolution commutes with the nearest upsample: it runs on the low-resolution map (a quarter of the
+        # work and of the tensor), its BatchNorm statistics are those of the upsampled map, and the tail pass reads it
+        # through the upsample
+        skip = self.skip_block.block[0]
+        half = up and _single(skip.kernel_size) == 1 and _single(skip.stride) == 1 and _single(skip.padding) == 0 and \
+            tail_takes_half_res(self.conv_block2.block[1], self.skip_block.block[1])
+        residual = run_conv(self.skip_block.block[0], x, upsample=up and not half)
         h = self.conv_block1(x, upsample=up)
         h = run_conv(self.conv_block2.block[0], h)
         # BatchNorm(conv2) + BatchNorm(skip) -> add -> ReLU in one apply pass (both blocks have no activation of their own)
-        return run_norm_add_norm_act(self.conv_block2.block[1], h, self.skip_block.block[1], residual, ops.ACT_RELU)
+        return run_norm_add_norm_act(self.conv_block2.block[1], h, self.skip_block.block[1], residual, ops.ACT_RELU,
+                                     b_half=half)
 
     def init_weights(self):
         for blk in (self.conv_block1, self.conv_block2, self.skip_block):

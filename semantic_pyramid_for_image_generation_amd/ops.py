@@ -612,7 +612,7 @@ def _nchw(x):
     return N, C, x.numel() // (N * C)
 
 
-def _norm_stats(x, gamma, beta, kind, eps, bn_state):
+def _norm_stats(x, gamma, beta, kind, eps, bn_state, rep=1):
     """per-row (mean, rstd, scale, shift) of a training-mode norm; updates the BatchNorm running statistics."""
     N, C, HW = _nchw(x)
     rows = N * C
@@ -623,7 +623,7 @@ def _norm_stats(x, gamma, beta, kind, eps, bn_state):
     if bn_state is not None:
         rm, rv, nbt, momentum = bn_state
     check(L.sempyr_norm_stats(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(),
-                              _p(rm), _p(rv), _p(nbt), momentum, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
+                              _p(rm), _p(rv), _p(nbt), momentum, rep, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
           "sempyr_norm_stats")
     if bn_state is not None:      # the kernel updated the buffers through raw pointers: tell version-keyed caches
         torch.autograd.graph.increment_version(rm)
@@ -670,36 +670,45 @@ class _NormAddNormAct(Function):
     two norm passes and an add.  The backward is composed of the single-norm pieces."""
 
     @staticmethod
-    def forward(ctx, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b):
+    def forward(ctx, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b,
+                b_half=False):
         a = _req(a, "norm input"); b = _req(b, "norm input")
-        if a.shape != b.shape:
+        if b_half:
+            # b is the branch BEFORE a nearest x2 upsample (its 1x1 convolution commutes with the upsample): statistics on
+            # the low-resolution map (identical mean / biased variance; the unbiased running variance counts 4x the elements)
+            if a.dim() != 4 or tuple(a.shape) != (b.shape[0], b.shape[1], 2 * b.shape[2], 2 * b.shape[3]):
+                raise _lib.SempyrError("norm_add_norm_act: the half-resolution branch must have half the height and width")
+        elif a.shape != b.shape:
             raise _lib.SempyrError("norm_add_norm_act: shape mismatch")
         gamma_a = _req(gamma_a, "norm weight"); beta_a = _req(beta_a, "norm bias")
         gamma_b = _req(gamma_b, "norm weight"); beta_b = _req(beta_b, "norm bias")
         N, C, HW = _nchw(a)
         rows = N * C
         ra = _norm_stats(a, gamma_a, beta_a, kind, eps_a, state_a)
-        rb = _norm_stats(b, gamma_b, beta_b, kind, eps_b, state_b)
+        rb = _norm_stats(b, gamma_b, beta_b, kind, eps_b, state_b, 4 if b_half else 1)
         y = torch.empty_like(a)
         check(L.sempyr_affine2_act(a.data_ptr(), ra.data_ptr(), ra.data_ptr() + 8 * rows, ra.data_ptr() + 12 * rows,
                                    b.data_ptr(), rb.data_ptr(), rb.data_ptr() + 8 * rows, rb.data_ptr() + 12 * rows,
-                                   y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine2_act")
+                                   y.data_ptr(), rows, HW, act_kind, slope, a.shape[3] if b_half else 0, _stream()),
+              "sempyr_affine2_act")
         ctx.save_for_backward(a, b, y if act_kind != ACT_NONE else None, gamma_a, gamma_b, ra, rb)
-        ctx.cfg = (kind, act_kind, slope)
+        ctx.cfg = (kind, act_kind, slope, b_half)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         a, b, y, gamma_a, gamma_b, ra, rb = ctx.saved_tensors
-        kind, act_kind, slope = ctx.cfg
+        kind, act_kind, slope, b_half = ctx.cfg
         g = gy.contiguous()
         if y is not None:
             g = _apply(_ActBwd, g, y, act_kind, slope)
         ga, gga, gba = _apply(_NormActBwd, g, a, None, gamma_a, ra, kind, ACT_NONE, 0.0)
-        gb, ggb, gbb = _apply(_NormActBwd, g, b, None, gamma_b, rb, kind, ACT_NONE, 0.0)
+        # the adjoint of the nearest upsample (sum over each 2x2 window), then the norm's backward at the low resolution
+        g_b = _apply(_Pool2Down, g, 1.0) if b_half else g
+        gb, ggb, gbb = _apply(_NormActBwd, g_b, b, None, gamma_b, rb, kind, ACT_NONE, 0.0)
         if _INPUT_GRADS_ONLY:
             gga = gba = ggb = gbb = None
-        return ga, gga, gba, None, gb, ggb, gbb, None, None, None, None, None, None
+        return ga, gga, gba, None, gb, ggb, gbb, None, None, None, None, None, None, None
 
 
 class _NormActBwd(Function):
@@ -759,9 +768,14 @@ def norm_act(x, gamma, beta, kind, act_kind=ACT_NONE, slope=0.0, eps=1e-5, bn_st
 
 
 def norm_add_norm_act(a, gamma_a, beta_a, b, gamma_b, beta_b, kind, act_kind=ACT_NONE, slope=0.0, eps_a=1e-5, eps_b=1e-5,
-                      state_a=None, state_b=None):
-    """act(norm(a) + norm(b)) for two training-mode norm layers of the same kind (generator.py:54-57)."""
-    return _apply(_NormAddNormAct, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b)
+                      state_a=None, state_b=None, b_half=False):
+    """act(norm(a) + norm(b)) for two training-mode norm layers of the same kind (generator.py:54-57).  `b_half`: b has
+    half the resolution and stands for its nearest x2 upsample (BATCH norm only: the statistics of the upsampled map are
+    those of b)."""
+    if b_half and kind != NORM_BATCH:
+        raise _lib.SempyrError("norm_add_norm_act: a half-resolution branch is only defined for BatchNorm")
+    return _apply(_NormAddNormAct, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b,
+                  b_half)
 
 
 class _AffineRowAct(Function):

@@ -236,6 +236,33 @@ def test_norm_add_norm_act(dev, kind):
         assert rel_err(o, r) < 5e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 6, 10), (2, 5, 3, 7)])
+def test_norm_add_norm_act_half_resolution_branch(dev, shape):
+    """relu(BN(a) + BN(up2(b))) with b given BEFORE the nearest upsample: output, gradients and the running statistics
+    (whose unbiased variance counts the upsampled element count) against the composed torch ops on the upsampled map."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    N, C, h, w = shape
+    a = torch.randn(N, C, 2 * h, 2 * w, generator=g) * 2 + 0.5
+    b = torch.randn(N, C, h, w, generator=g) - 1.0
+    par = [torch.randn(C, generator=g) * 0.5 + 1 for _ in range(2)] + [torch.randn(C, generator=g) * 0.3 for _ in range(2)]
+    gy = torch.randn(a.shape, generator=g)
+    rm_r, rv_r = torch.zeros(C), torch.ones(C)
+    tr = [v.clone().requires_grad_(True) for v in (a, b, *par)]
+    bu = F.interpolate(tr[1], scale_factor=2, mode='nearest')
+    yr = F.relu(F.batch_norm(tr[0], None, None, tr[2], tr[4], True, 0.1, 1e-5) + F.batch_norm(bu, rm_r, rv_r, tr[3], tr[5], True, 0.1, 1e-5))
+    yr.backward(gy)
+    td = [v.clone().to(dev).requires_grad_(True) for v in (a, b, *par)]
+    rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    y = ops.norm_add_norm_act(td[0], td[2], td[4], td[1], td[3], td[5], ops.NORM_BATCH, ops.ACT_RELU,
+                              state_b=(rm, rv, nbt, 0.1), b_half=True)
+    y.backward(gy.to(dev))
+    assert rel_err(y, yr) < 5e-5
+    for o, r in zip(td, tr):
+        assert rel_err(o.grad, r.grad) < 5e-5
+    assert rel_err(rm, rm_r) < 1e-5 and rel_err(rv, rv_r) < 1e-5 and int(nbt) == 1
+
+
 def test_batchnorm_running_stats(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(9)
