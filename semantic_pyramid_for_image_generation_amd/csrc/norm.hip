@@ -655,21 +655,156 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
     }
 }
 
-// ggamma[c] = sum_n sum gy'*xhat, gbeta[c] = sum_n sum gy' from the shifted row sums (double math, as the finalize kernel)
-__global__ void norm_bwd_channel_kernel(const float* __restrict__ sums, const float* __restrict__ rstd_row, int N, int C,
-                                        int len, float* __restrict__ ggamma, float* __restrict__ gbeta)
+// Register-resident forms: a row of TPR * 4 * NV4 elements is loaded ONCE (NV4 float4 per thread, all loads in flight
+// together) and the two reductions and the apply step work on registers -- no second or third sweep.
+template <int TPR, int NV4>
+__global__ __launch_bounds__(256) void instnorm_fwd_reg_kernel(const float* __restrict__ x, int rows, int C, float eps,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int act, float slope, float* __restrict__ y,
+                                                               float* __restrict__ rowbuf)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[8];
+    constexpr int RPB = 256 / TPR;
+    constexpr int LEN = TPR * 4 * NV4;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)(live ? row : 0) * LEN);
+    float4 v[NV4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) v[i] = x4[t + i * TPR];
+    float s[1] = {0.f};
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) s[0] += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    row_reduce<TPR, 1>(s, sh);
+    const float mean = s[0] / (float)LEN;
+    float q[1] = {0.f};
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q[0] += (a * a + b * b) + (c * c + d * d);
+    }
+    row_reduce<TPR, 1>(q, sh);
+    if (!live) return;
+    const float rstd = 1.0f / sqrtf(q[0] / (float)LEN + eps);
+    const int c = row % C;
+    const float sc = rstd * gamma[c], sf = beta[c];
+    if (t == 0) { rowbuf[row] = mean; rowbuf[rows + row] = rstd; rowbuf[2 * rows + row] = sc; rowbuf[3 * rows + row] = sf; }
+    float4* y4 = reinterpret_cast<float4*>(y + (size_t)row * LEN);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        float4 o;
+        o.x = act_apply((v[i].x - mean) * sc + sf, act, slope); o.y = act_apply((v[i].y - mean) * sc + sf, act, slope);
+        o.z = act_apply((v[i].z - mean) * sc + sf, act, slope); o.w = act_apply((v[i].w - mean) * sc + sf, act, slope);
+        y4[t + i * TPR] = o;
+    }
+}
+
+template <int TPR, int NV4>
+__global__ __launch_bounds__(256) void instnorm_bwd_reg_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                               const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean_row, const float* __restrict__ rstd_row,
+                                                               int rows, int C, int act, float slope,
+                                                               float* __restrict__ gx, float* __restrict__ sums)
+{
+    __shared__ float sh[12];
+    constexpr int RPB = 256 / TPR;
+    constexpr int LEN = TPR * 4 * NV4;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < rows;
+    const size_t base = (size_t)(live ? row : 0) * LEN;
+    const float mean = mean_row[live ? row : 0];
+    const float4* g4 = reinterpret_cast<const float4*>(gy + base);
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    float4 g[NV4], xv[NV4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) { g[i] = g4[t + i * TPR]; xv[i] = x4[t + i * TPR]; }
+    float Kg = gy[base];
+    if (act != SEMPYR_ACT_NONE) {
+        const float4* y4 = reinterpret_cast<const float4*>(y + base);
+        Kg *= act_deriv(y[base], act, slope);
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const float4 yv = y4[t + i * TPR];
+            g[i].x *= act_deriv(yv.x, act, slope); g[i].y *= act_deriv(yv.y, act, slope);
+            g[i].z *= act_deriv(yv.z, act, slope); g[i].w *= act_deriv(yv.w, act, slope);
+        }
+    }
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+        const float a = g[i].x - Kg, b = g[i].y - Kg, c = g[i].z - Kg, d = g[i].w - Kg;
+        s[0] += (a + b) + (c + d);
+        s[1] += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+        s[2] += (a * xv[i].x + b * xv[i].y) + (c * xv[i].z + d * xv[i].w);
+    }
+    row_reduce<TPR, 3>(s, sh);
+    if (!live) return;
+    if (t == 0) { sums[row] = Kg; sums[rows + row] = s[0]; sums[2 * rows + row] = s[1]; sums[3 * rows + row] = s[2]; }
+    const double r = rstd_row[row], gm = gamma[row % C];
+    const double G1 = (double)Kg * LEN + (double)s[0];
+    const double G2 = ((double)s[2] + (double)Kg * (double)s[1]) * r;
+    const float a = (float)(r * gm), b = (float)(-r * r * (gm * G2 / (double)LEN)), c = (float)(-r * (gm * G1 / (double)LEN));
+    float4* o4 = reinterpret_cast<float4*>(gx + base);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        float4 o;
+        o.x = a * g[i].x + b * xv[i].x + c; o.y = a * g[i].y + b * xv[i].y + c;
+        o.z = a * g[i].z + b * xv[i].z + c; o.w = a * g[i].w + b * xv[i].w + c;
+        o4[t + i * TPR] = o;
+    }
+}
+
+// host dispatch of the register-resident kernels: returns false when the row length has no instantiation
+template <int TPR>
+bool launch_instnorm_fwd_reg(int nv4, dim3 grid, hipStream_t st, const float* x, int rows, int C, float eps, const float* gamma,
+                             const float* beta, int act, float slope, float* y, float* rowbuf)
+{
+    switch (nv4) {
+#define SEMPYR_CASE(NV) case NV: hipLaunchKernelGGL((instnorm_fwd_reg_kernel<TPR, NV>), grid, dim3(256), 0, st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf); return true;
+        SEMPYR_CASE(1) SEMPYR_CASE(2) SEMPYR_CASE(4) SEMPYR_CASE(8) SEMPYR_CASE(16)
+#undef SEMPYR_CASE
+        default: return false;
+    }
+}
+template <int TPR>
+bool launch_instnorm_bwd_reg(int nv4, dim3 grid, hipStream_t st, const float* gy, const float* y, const float* x,
+                             const float* gamma, const float* mean_row, const float* rstd_row, int rows, int C, int act,
+                             float slope, float* gx, float* sums)
+{
+    switch (nv4) {
+#define SEMPYR_CASE(NV) case NV: hipLaunchKernelGGL((instnorm_bwd_reg_kernel<TPR, NV>), grid, dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums); return true;
+        SEMPYR_CASE(1) SEMPYR_CASE(2) SEMPYR_CASE(4) SEMPYR_CASE(8)
+#undef SEMPYR_CASE
+        default: return false;
+    }
+}
+
+// ggamma[c] = sum_n sum gy'*xhat, gbeta[c] = sum_n sum gy' from the shifted row sums (double math, as the finalize kernel)
+// FIN_LPG lanes per channel (one thread per channel walking its N rows was a chain of dependent L2 round trips: 9 us).
+__global__ __launch_bounds__(256) void norm_bwd_channel_kernel(const float* __restrict__ sums, const float* __restrict__ rstd_row,
+                                                               int N, int C, int len, float* __restrict__ ggamma,
+                                                               float* __restrict__ gbeta)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = idx / FIN_LPG, l = idx % FIN_LPG;
+    const bool live = c < C;                       // uniform per 16-lane group; dead groups still join the shuffles
     const int rows = N * C;
     double a = 0.0, b = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const int row = n * C + c;
-        a += (double)sums[row] * len + (double)sums[rows + row];
-        b += ((double)sums[3 * rows + row] + (double)sums[row] * (double)sums[2 * rows + row]) * (double)rstd_row[row];
+    if (live) {
+        for (int n = l; n < N; n += FIN_LPG) {
+            const int row = n * C + c;
+            a += (double)sums[row] * len + (double)sums[rows + row];
+            b += ((double)sums[3 * rows + row] + (double)sums[row] * (double)sums[2 * rows + row]) * (double)rstd_row[row];
+        }
     }
-    if (gbeta) gbeta[c] = (float)a;
-    if (ggamma) ggamma[c] = (float)b;
+    a = lpg_sum_d(a); b = lpg_sum_d(b);
+    if (live && l == 0) {
+        if (gbeta) gbeta[c] = (float)a;
+        if (ggamma) ggamma[c] = (float)b;
+    }
 }
 
 } // namespace
@@ -708,6 +843,10 @@ extern "C" int sempyr_norm_fwd(int kind, const float* x, int N, int C, int HW, f
     if (kind == SEMPYR_NORM_INSTANCE && HW <= INST_FUSED_MAX_LEN && inst_fused_on()) {
         hipStream_t st = (hipStream_t)stream;
         const int vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+        bool done = false;
+        if (vec && HW >= 2048 && HW % 1024 == 0) done = launch_instnorm_fwd_reg<256>(HW / 1024, dim3(rows), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
+        else if (vec && HW < 2048 && HW % 256 == 0) done = launch_instnorm_fwd_reg<64>(HW / 256, dim3(ceil_div(rows, 4)), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
+        if (done) { SEMPYR_CHECK_LAUNCH(); return 0; }
         if (HW >= 2048) hipLaunchKernelGGL(instnorm_fwd_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, C, HW, vec, eps, gamma, beta, act, slope, y, rowbuf);
         else hipLaunchKernelGGL(instnorm_fwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, C, HW, vec, eps, gamma, beta, act, slope, y, rowbuf);
         SEMPYR_CHECK_LAUNCH();
@@ -743,11 +882,16 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     const int vec = (HW % 4 == 0) && aligned16(gy) && aligned16(x) && aligned16(gx) && (act == SEMPYR_ACT_NONE || aligned16(y));
     float* sums = scratch;
     if (kind == SEMPYR_NORM_INSTANCE && HW <= INST_FUSED_MAX_LEN && inst_fused_on()) {
+        bool done = false;
+        if (vec && HW >= 2048 && HW % 1024 == 0) done = launch_instnorm_bwd_reg<256>(HW / 1024, dim3(rows), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
+        else if (vec && HW < 2048 && HW % 256 == 0) done = launch_instnorm_bwd_reg<64>(HW / 256, dim3(ceil_div(rows, 4)), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
+        if (!done) {
         if (HW >= 2048) hipLaunchKernelGGL(instnorm_bwd_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);
         else hipLaunchKernelGGL(instnorm_bwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);
+        }
         SEMPYR_CHECK_LAUNCH();
         if (ggamma || gbeta) {
-            hipLaunchKernelGGL(norm_bwd_channel_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, sums, rstd_row, N, C, HW, ggamma, gbeta);
+            hipLaunchKernelGGL(norm_bwd_channel_kernel, dim3(ceil_div((long long)C * FIN_LPG, 256)), dim3(256), 0, st, sums, rstd_row, N, C, HW, ggamma, gbeta);
             SEMPYR_CHECK_LAUNCH();
         }
         return 0;
