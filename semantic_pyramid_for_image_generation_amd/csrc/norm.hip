@@ -271,12 +271,15 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(int kind, const 
             cB[row] = (float)(-r * r * sbar);
             cC[row] = (float)(-r * abar);
         }
-    } else if (idx < ng * FIN_LPG + C) {
-        const int c = idx - ng * FIN_LPG;
+    } else if (idx < (ng + C) * FIN_LPG) {         // FIN_LPG lanes per channel as well (ng * FIN_LPG is a multiple of 16:
+        const int c = idx / FIN_LPG - ng, l = idx % FIN_LPG;      // a 16-lane group never straddles the two branches)
         double a = 0.0, b = 0.0;
-        for (int n = 0; n < N; ++n) { a += G1(n * C + c); b += G2(n * C + c); }
-        if (gbeta) gbeta[c] = (float)a;
-        if (ggamma) ggamma[c] = (float)b;
+        for (int n = l; n < N; n += FIN_LPG) { a += G1(n * C + c); b += G2(n * C + c); }
+        a = lpg_sum_d(a); b = lpg_sum_d(b);
+        if (l == 0) {
+            if (gbeta) gbeta[c] = (float)a;
+            if (ggamma) ggamma[c] = (float)b;
+        }
     }
 }
 
@@ -900,7 +903,7 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
     SEMPYR_CHECK_LAUNCH();
-    const int nthreads = num_groups(kind, N, C) * FIN_LPG + C;
+    const int nthreads = (num_groups(kind, N, C) + C) * FIN_LPG;
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(nthreads, 256)), dim3(256), 0, st, kind, sums, N, C, HW, gamma,
                        rstd_row, cA, cB, cC, ggamma, gbeta);
     SEMPYR_CHECK_LAUNCH();
