@@ -239,8 +239,10 @@ int sempyr_fill_scalar(const float* g, float scale, float* y, int64_t n, void* s
 int sempyr_l1_mean(const float* a, const float* b, const float* mask, int64_t n, float* out, float* scratch, void* stream);
 int sempyr_l1_mean_bwd(const float* a, const float* b, const float* mask, const float* gout, int64_t n,
                        float* ga, float* gb, void* stream);
-/* norms[r] = ||grad[r,:]||_2 ; *gp = mean (norms-1)^2 : norm + one_mean_gp train_model.py:58-66 */
-int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, void* stream);
+/* norms[r] = ||grad[r,:]||_2 ; *gp = mean (norms-1)^2 : norm + one_mean_gp train_model.py:58-66. scratch (optional,
+ * rows*SEMPYR_GP_SPLIT floats): long rows of a small batch are reduced by SEMPYR_GP_SPLIT workgroups each. */
+#define SEMPYR_GP_SPLIT 48
+int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, float* scratch, void* stream);
 /* out = grad * (*gout) * (2/rows) * (norm-1)/norm : its backward (feeds the double backward) */
 int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int rows, int len, float* out, void* stream);
 /* out[c] = scale * sum_{n,hw} x[n][c][hw] : conv bias gradient ; scratch = N*C floats ; accumulate != 0: out[c] += that */

@@ -82,7 +82,7 @@ SIGNATURES = {
     "sempyr_fill_scalar": [_P, c_float, _P, c_int64, _P],
     "sempyr_l1_mean": [_P, _P, _P, c_int64, _P, _P, _P],
     "sempyr_l1_mean_bwd": [_P, _P, _P, _P, c_int64, _P, _P, _P],
-    "sempyr_gp_fwd": [_P, c_int, c_int, _P, _P, _P],
+    "sempyr_gp_fwd": [_P, c_int, c_int, _P, _P, _P, _P],
     "sempyr_gp_bwd": [_P, _P, _P, c_int, c_int, _P, _P],
     "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P],
     "sempyr_profile_begin": [c_int],

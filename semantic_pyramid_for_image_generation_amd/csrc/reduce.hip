@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
 // per-row sum of squares -> L2 norm
 template <int TPR>
 __global__ __launch_bounds__(256) void row_l2norm_kernel(const float* __restrict__ x, int rows, int len, int vec,
-                                                         float* __restrict__ norms)
+                                                         float* __restrict__ norms, int take_sqrt)
 {
     __shared__ float sh[4];
     constexpr int RPB = 256 / TPR;
@@ -101,15 +101,28 @@ __global__ __launch_bounds__(256) void row_l2norm_kernel(const float* __restrict
         }
     }
     if (TPR == 256) s = block_sum_256(s, sh); else s = wave_sum(s);
-    if (live && t == 0) norms[row] = sqrtf(s);
+    if (live && t == 0) norms[row] = take_sqrt ? sqrtf(s) : s;
 }
 
-// gp = mean_r (norm_r - 1)^2
-__global__ __launch_bounds__(256) void gp_final_kernel(const float* __restrict__ norms, int rows, float* __restrict__ gp)
+// gp = mean_r (norm_r - 1)^2.  split > 1: `parts` holds `split` partial sums of squares per row (a 196 608-element row per
+// sample would otherwise keep only `rows` = 16 workgroups busy: 54 us); the norms are finished here, in a fixed order.
+__global__ __launch_bounds__(256) void gp_final_kernel(float* __restrict__ norms, const float* __restrict__ parts, int split,
+                                                       int rows, float* __restrict__ gp)
 {
     __shared__ float sh[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < rows; i += 256) { const float d = norms[i] - 1.f; s += d * d; }
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        float nr;
+        if (split > 1) {
+            float a = 0.f;
+            for (int j = 0; j < split; ++j) a += parts[(size_t)i * split + j];
+            nr = sqrtf(a);
+            norms[i] = nr;
+        } else {
+            nr = norms[i];
+        }
+        const float d = nr - 1.f; s += d * d;
+    }
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) *gp = s / (float)rows;
 }
@@ -219,15 +232,19 @@ extern "C" int sempyr_l1_mean_bwd(const float* a, const float* b, const float* m
     return 0;
 }
 
-extern "C" int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, void* stream)
+extern "C" int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, float* scratch, void* stream)
 {
     if (!grad || !norms || !gp || rows < 1 || len < 1) SEMPYR_FAIL("gp_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int vec = (len % 4 == 0) && aligned16(grad);
-    if (len >= 2048) hipLaunchKernelGGL(row_l2norm_kernel<256>, dim3(rows), dim3(256), 0, st, grad, rows, len, vec, norms);
-    else hipLaunchKernelGGL(row_l2norm_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, grad, rows, len, vec, norms);
+    int split = 1;
+    if (scratch && rows < 256 && len % (SEMPYR_GP_SPLIT * 4) == 0 && len / SEMPYR_GP_SPLIT >= 2048) split = SEMPYR_GP_SPLIT;
+    if (split > 1)          // `split` sub-rows per row, each reduced by its own workgroup
+        hipLaunchKernelGGL(row_l2norm_kernel<256>, dim3(rows * split), dim3(256), 0, st, grad, rows * split, len / split, vec, scratch, 0);
+    else if (len >= 2048) hipLaunchKernelGGL(row_l2norm_kernel<256>, dim3(rows), dim3(256), 0, st, grad, rows, len, vec, norms, 1);
+    else hipLaunchKernelGGL(row_l2norm_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, grad, rows, len, vec, norms, 1);
     SEMPYR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(256), 0, st, norms, rows, gp);
+    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(256), 0, st, norms, (const float*)scratch, split, rows, gp);
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }

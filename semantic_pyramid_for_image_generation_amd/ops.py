@@ -1207,7 +1207,9 @@ class _GPLoss(Function):
         n = grad.numel() // rows
         norms = torch.empty(rows, dtype=torch.float32, device=grad.device)
         gp = torch.empty((), dtype=torch.float32, device=grad.device)
-        check(L.sempyr_gp_fwd(grad.data_ptr(), rows, n, norms.data_ptr(), gp.data_ptr(), _stream()), "sempyr_gp_fwd")
+        scratch = torch.empty(rows * 48, dtype=torch.float32, device=grad.device)       # SEMPYR_GP_SPLIT partials per row
+        check(L.sempyr_gp_fwd(grad.data_ptr(), rows, n, norms.data_ptr(), gp.data_ptr(), scratch.data_ptr(), _stream()),
+              "sempyr_gp_fwd")
         ctx.save_for_backward(grad, norms)
         return gp
 
