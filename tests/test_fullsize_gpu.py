@@ -24,6 +24,11 @@ CASES = [
     ("D.b3 4x4 s2", (16, 128, 32, 32, 256, 4, 2, 1, 0, True), None, False),
     ("C.stem 7x7 s2", (16, 3, 256, 256, 64, 7, 2, 3, 0, False), None, False),
     ("C.l2 3x3", (16, 128, 32, 32, 128, 3, 1, 1, 0, False), None, False),
+    # deep layers on small planes: 64x64 tiles (patch kernel on 8x8 / 16x16 planes, 4-phase input gradients, split-K)
+    ("C.l4 3x3 @8", (16, 512, 8, 8, 512, 3, 1, 1, 0, False), None, False),
+    ("G.b3 ups @8", (16, 512, 8, 8, 256, 3, 1, 1, 1, False), None, False),
+    ("D.b5 4x4 s2 @8", (16, 512, 8, 8, 512, 4, 2, 1, 0, True), None, False),
+    ("D.b4 4x4 s2 batch 32", (32, 256, 16, 16, 512, 4, 2, 1, 0, True), None, False),
 ]
 
 
