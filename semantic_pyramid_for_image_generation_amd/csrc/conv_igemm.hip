@@ -1081,6 +1081,105 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     wp[i] = (s >= 0 && m < M) ? w[(size_t)s + (size_t)m * mstride] : 0.f;
 }
 
+
+// Weight gradient of an RGB head (3x3 / stride 1 / pad 1, <= 4 output channels: the generator's last conv) on the vector
+// ALU: padding M = 3 to a 32-row MFMA tile wastes 10x the matrix work (0.55 ms, 6.6 TFLOP/s).  A workgroup owns RGBW_ROWS image
+// rows of one sample and RGBW_CG input channels; a thread owns one pixel column, walks down its rows with a rolling 3x3
+// window per channel (3 new loads per channel and row) and keeps NM x 9 x RGBW_CG accumulators; the workgroup's sums go
+// to `part` [strip][C][NM*9] and rgbw_reduce_kernel adds the strips in a fixed order.
+constexpr int RGBW_ROWS = 32, RGBW_CG = 4;
+template <int NM>
+__global__ __launch_bounds__(256) void rgb_wgrad3x3_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                           int C, int H, int W, float* __restrict__ part)
+{
+    __shared__ float sh[4][NM * 9 * RGBW_CG];
+    const int nstrip_img = (H + RGBW_ROWS - 1) / RGBW_ROWS;
+    const int cgroups = C / RGBW_CG;
+    int id = blockIdx.x;
+    const int cg = id % cgroups; id /= cgroups;
+    const int strip = id % nstrip_img; const int b = id / nstrip_img;
+    const int rpp = 256 / W;                                   // image rows covered by one pass of the workgroup
+    const int col = threadIdx.x % W, rsub = threadIdx.x / W;
+    const int y0 = strip * RGBW_ROWS;
+    const int yend = min(y0 + RGBW_ROWS, H);
+    const float* xb = x + ((size_t)b * C + (size_t)cg * RGBW_CG) * H * W;
+    const float* gb = gy + (size_t)b * NM * H * W;
+    float acc[RGBW_CG][NM][9];
+#pragma unroll
+    for (int c = 0; c < RGBW_CG; ++c)
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c][m][t] = 0.f;
+    const bool lok = col > 0, rok = col < W - 1;
+    auto load_row = [&](int c, int yy, float (&r)[3]) {        // x[c][yy][col-1 .. col+1], zero outside the image
+        if (yy < 0 || yy >= H) { r[0] = r[1] = r[2] = 0.f; return; }
+        const float* q = xb + (size_t)c * H * W + (size_t)yy * W + col;
+        r[1] = q[0]; r[0] = lok ? q[-1] : 0.f; r[2] = rok ? q[1] : 0.f;
+    };
+    if (threadIdx.x < rpp * W) {
+        float win[RGBW_CG][3][3];
+        for (int y = y0 + rsub; y < yend; y += rpp) {
+            if (rpp == 1 && y > y0) {                          // rolling window: rows y-1, y are already there
+#pragma unroll
+                for (int c = 0; c < RGBW_CG; ++c) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { win[c][0][k] = win[c][1][k]; win[c][1][k] = win[c][2][k]; }
+                    load_row(c, y + 1, win[c][2]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < RGBW_CG; ++c) { load_row(c, y - 1, win[c][0]); load_row(c, y, win[c][1]); load_row(c, y + 1, win[c][2]); }
+            }
+            float g[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) g[m] = gb[(size_t)m * H * W + (size_t)y * W + col];
+#pragma unroll
+            for (int c = 0; c < RGBW_CG; ++c)
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc[c][m][t] = fmaf(g[m], win[c][t / 3][t % 3], acc[c][m][t]);
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < RGBW_CG; ++c)
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = wave_sum(acc[c][m][t]);
+                if (lane == 0) sh[wave][(c * NM + m) * 9 + t] = v;
+            }
+    __syncthreads();
+    if (threadIdx.x < NM * 9 * RGBW_CG) {
+        const int i = threadIdx.x;
+        const float v = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+        const int c = i / (NM * 9), rem = i - c * (NM * 9);
+        // part[(b * nstrip_img + strip)][channel][m * 9 + t]
+        part[((size_t)(b * nstrip_img + strip) * C + (size_t)cg * RGBW_CG + c) * (NM * 9) + rem] = v;
+    }
+}
+
+// gw[m][ci][t] (torch order) = sum over strips of part[strip][ci][m*9 + t]
+__global__ __launch_bounds__(256) void rgbw_reduce_kernel(const float* __restrict__ part, int nstrips, int C, int NM,
+                                                          float* __restrict__ gw, int accumulate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;              // index into [ci][m*9 + t]
+    const int per = NM * 9;
+    if (i >= C * per) return;
+    float a0 = 0.f, a1 = 0.f;
+    int s = 0;
+    for (; s + 1 < nstrips; s += 2) { a0 += part[(size_t)s * C * per + i]; a1 += part[(size_t)(s + 1) * C * per + i]; }
+    if (s < nstrips) a0 += part[(size_t)s * C * per + i];
+    const int ci = i / per, rem = i - ci * per;
+    const int m = rem / 9, t = rem - m * 9;
+    const size_t dst = ((size_t)m * C + ci) * 9 + t;
+    const float sum = a0 + a1;
+    gw[dst] = accumulate ? gw[dst] + sum : sum;
+}
+
 // The same for many weight tensors in ONE launch (all packed layouts of a module, refreshed right behind its optimizer
 // step instead of one small launch in front of each convolution of the next pass).  The item table travels in the kernel
 // arguments; a workgroup finds its item by a binary search over the items' first-workgroup index.
@@ -1433,6 +1532,15 @@ int launch_cfg(int cfg, const IgemmParams& p, int splits, bool uniform_tap, hipS
 
 } // namespace
 
+namespace {
+// Shapes served by rgb_wgrad3x3_kernel
+inline bool rgb_wgrad_ok(const sempyr_conv_desc* d) {
+    static const int enabled = env_int("SEMPYR_RGB_WGRAD", 1);
+    return enabled && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->ups == 0 && d->Cout <= 4 &&
+           d->Cin % RGBW_CG == 0 && d->Win <= 256 && 256 % d->Win == 0;
+}
+}  // namespace
+
 extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_conv_plan* plan)
 {
     Geometry g;
@@ -1506,6 +1614,10 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         int cps;
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(Nn, bn), plan->Kpad[0] / BK, plan->splits[0], cps, target_blocks_wgrad());
         plan->workspace_bytes = (long long)plan->splits[0] * d->Cout * Nn * 4;
+        if (rgb_wgrad_ok(d)) {
+            const long long need = (long long)d->B * ceil_div(d->Hin, RGBW_ROWS) * d->Cin * d->Cout * 9 * 4;
+            if (need > plan->workspace_bytes) plan->workspace_bytes = need;
+        }
     }
     return 0;
 }
@@ -1755,6 +1867,35 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     hipStream_t st = (hipStream_t)stream;
     const int T = d->kh * d->kw;
     const int Nn = pl.tab_entries;
+    if (rgb_wgrad_ok(d)) {
+        const int nstrips = d->B * ceil_div(d->Hin, RGBW_ROWS);
+        dim3 grid((unsigned)(nstrips * (d->Cin / RGBW_CG)));
+        float* part = (float*)ws;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_prof.on) {
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            if (g_prof.used + 2 <= g_prof.events.size()) {
+                e0 = g_prof.events[g_prof.used]; e1 = g_prof.events[g_prof.used + 1];
+                g_prof.used += 2;
+                const double flops = 2.0 * (double)d->Cout * (double)(d->Cin * T) * (double)d->B * d->Hin * d->Win;
+                g_prof.flops += flops;
+                g_prof.recs.push_back({9, 4, 256, d->Cout, d->Cin * T, d->B * d->Hin * d->Win, 1, 1, flops});
+            }
+        }
+        if (e0) (void)hipEventRecord(e0, st);
+        switch (d->Cout) {
+            case 1: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<1>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
+            case 2: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<2>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
+            case 3: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<3>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
+            default: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<4>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
+        }
+        if (e1) (void)hipEventRecord(e1, st);
+        SEMPYR_CHECK_LAUNCH();
+        hipLaunchKernelGGL(rgbw_reduce_kernel, dim3(ceil_div(d->Cin * d->Cout * 9, 256)), dim3(256), 0, st,
+                           (const float*)part, nstrips, d->Cin, d->Cout, gw, accumulate ? 1 : 0);
+        SEMPYR_CHECK_LAUNCH();
+        return 0;
+    }
     IgemmParams p{};
     p.A = gy; p.X = x; p.ktab = reinterpret_cast<const int2*>(ktab);
     p.M = d->Cout; p.Mpad = pl.Mpad; p.N = Nn; p.K = pl.K[0]; p.Kpad = pl.Kpad[0];

@@ -40,6 +40,8 @@ CONV_CASES = [
     (1, 6, 64, 64, 4, 3, 1, 1, 0, False),       # 4 output rows
     (1, 8, 16, 256, 3, 3, 1, 1, 0, True),       # width 256: one wave per image row, neighbour pixels by lane shifts
     (1, 3, 16, 256, 8, 3, 1, 1, 0, True),       # ... and as an input gradient
+    (1, 8, 40, 128, 4, 3, 1, 1, 0, True),       # VALU weight-gradient kernel: 4 output rows, ragged last row strip
+    (2, 4, 70, 256, 3, 3, 1, 1, 0, True),       # ... rolling-window path (width 256), three strips
 ]
 
 
