@@ -98,13 +98,14 @@ int sempyr_conv2d_pack_weights_many(const sempyr_pack_item* items, int n_items, 
 /* y[B,Cout,Ho,Wo] = act(scale[Cout] * conv(x, w) + bias[Cout] + res[B,Cout,Ho,Wo]); scale, bias and res are each optional
  * (NULL = absent). scale + bias fold an eval-mode BatchNorm2d into the epilogue and res the identity branch of a ResNet
  * BasicBlock (the frozen classifier, classifier.py:34-40 under .eval(); the generator under eval_model.py). They are
- * rejected for Cout <= 4 and together with y_pooled. act is a SEMPYR_ACT_* code applied in the
+ * rejected for Cout <= 4 and together with y_pooled. res_half != 0: res is [B,Cout,Ho/2,Wo/2] and is read through a nearest
+ * x2 upsample (the 1x1 skip branch of an upsampling block computed before the upsample, generator.py:44,60-62). act is a SEMPYR_ACT_* code applied in the
  * kernel epilogue (`conv -> LeakyReLU` of the critic stem discriminator.py:106-107, `conv -> Tanh` of the generator head
  * generator.py:116-120), slope the LeakyReLU slope. y_pooled (optional, [B,Cout,Ho/2,Wo/2]) also receives
  * AvgPool2d(2)(y) (discriminator.py:109), computed in the same epilogue when the launch is a single pass. */
 int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wpacked_fwd,
                       const int32_t* ktab_fwd_dev, const float* bias, const float* scale, const float* res,
-                      int act, float slope, float* y,
+                      int res_half, int act, float slope, float* y,
                       float* y_pooled, void* workspace, size_t workspace_bytes, void* stream);
 
 /* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a

@@ -56,7 +56,7 @@ SIGNATURES = {
     "sempyr_conv2d_tables": [_DESC, c_int, _P, _P],
     "sempyr_conv2d_pack_weights": [_DESC, c_int, _P, _P, _P, _P],
     "sempyr_conv2d_pack_weights_many": [ctypes.POINTER(PackItem), c_int, _P],
-    "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_size_t, _P],
+    "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, _P, c_size_t, _P],
     "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P],

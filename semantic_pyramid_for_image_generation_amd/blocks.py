@@ -74,15 +74,22 @@ def run_norm(layer, x, act_kind=ops.ACT_NONE, slope=0.0, res=None):
     return ops.add_act(y, res, act_kind, slope) if res is not None else y
 
 
-def run_conv_norm(conv, norm, x, act_kind=ops.ACT_NONE, slope=0.0, res=None, upsample=False):
+def fuses_conv_norm(conv, norm):
+    """True when run_conv_norm runs `conv` + `norm` as one launch (bias-free Conv2d + eval-mode BatchNorm2d)."""
+    return (isinstance(conv, nn.Conv2d) and conv.bias is None and conv.out_channels > 4 and isinstance(norm, nn.BatchNorm2d)
+            and not norm.training and norm.track_running_stats and norm.affine)
+
+
+def run_conv_norm(conv, norm, x, act_kind=ops.ACT_NONE, slope=0.0, res=None, upsample=False, res_half=False):
     """act(norm(conv(x)) [+ res]).  A bias-free Conv2d followed by an eval-mode BatchNorm2d (every conv of the frozen
     ResNet18 classifier; the generator under .eval()) is one launch: scale / shift, residual and activation run in the
     convolution's epilogue.  Everything else is run_conv followed by run_norm."""
-    if (isinstance(conv, nn.Conv2d) and conv.bias is None and conv.out_channels > 4 and isinstance(norm, nn.BatchNorm2d)
-            and not norm.training and norm.track_running_stats and norm.affine):
+    if fuses_conv_norm(conv, norm):
         return ops.conv_bn_eval_act(x, conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps,
                                     _single(conv.stride), _single(conv.padding), upsample=upsample, res=res,
-                                    act_kind=act_kind, slope=slope)
+                                    act_kind=act_kind, slope=slope, res_half=res_half)
+    if res_half:
+        raise NotImplementedError("a half-resolution residual needs the fused conv + eval-BatchNorm path (see fuses_conv_norm)")
     return run_norm(norm, run_conv(conv, x, upsample=upsample), act_kind, slope, res=res)
 
 

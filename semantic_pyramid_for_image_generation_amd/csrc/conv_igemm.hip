@@ -80,6 +80,7 @@ struct IgemmParams {
     float* Out;            // output tensor, or slab base when splits > 1 / WGRAD
     const float* scale;    // per-m scale applied before the bias (eval-mode BatchNorm folded into the epilogue), or null
     const float* res;      // residual in the output's layout, added before the activation, or null
+    int res_half;          // 1: res has half the output's height and width and is read through a nearest x2 upsample
     const float* bias;     // per-m bias (only applied when splits == 1, GATHER mode)
     const int2* ktab;      // gather table: GATHER -> indexed by k ; WGRAD -> indexed by n
     int M, Mpad, N, K, Kpad;
@@ -437,14 +438,16 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
                 if (n >= pN) continue;
                 int b, qy, qx;
                 decode_pixel(n, pQHW, pQW, p.quad, b, qy, qx);
-                const float* rp = p.res + (size_t)b * p.OCHW + (qy * p.OSY + pOPY) * p.OW + qx * p.OSX + pOPX;
+                const float* rp = p.res_half ? p.res + (size_t)b * (p.OCHW >> 2) + (qy >> 1) * (p.OW >> 1) + (qx >> 1)
+                                             : p.res + (size_t)b * p.OCHW + (qy * p.OSY + pOPY) * p.OW + qx * p.OSX + pOPX;
+                const int rstride = p.res_half ? (p.OHW >> 2) : p.OHW;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
 #pragma unroll
                     for (int r16 = 0; r16 < 16; ++r16) {
                         const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
-                        acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * p.OHW];
+                        acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * rstride];
                     }
                 }
             }
@@ -732,14 +735,17 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-            const float* rp = p.res + (size_t)tb * p.OCHW + (n - tb * p.QHW);
+            const int rr = n - tb * p.QHW, ry = rr / p.QW, rx = rr - ry * p.QW;
+            const float* rp = p.res_half ? p.res + (size_t)tb * (p.OCHW >> 2) + (ry >> 1) * (p.OW >> 1) + (rx >> 1)
+                                         : p.res + (size_t)tb * p.OCHW + rr;
+            const int rstride = p.res_half ? (p.OHW >> 2) : p.OHW;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
 #pragma unroll
                 for (int r16 = 0; r16 < 16; ++r16) {
                     const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
-                    acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * p.OHW];
+                    acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * rstride];
                 }
             }
         }
@@ -956,7 +962,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bias, int splits,
                                                             long long slab_stride, int total4, int OHW, int OC,
                                                             int act, float slope, const float* __restrict__ scale,
-                                                            const float* __restrict__ res)
+                                                            const float* __restrict__ res, int res_w)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
@@ -978,7 +984,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         a.z += bias[((e + 2) / OHW) % OC]; a.w += bias[((e + 3) / OHW) % OC];
     }
     if (res) {
-        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        float4 r;
+        if (res_w > 0) {                                  // half-resolution residual (OW % 4 == 0: the 4 elements share a row)
+            const int e = i * 4, plane = e / OHW, rem = e - plane * OHW;
+            const int yy = rem / res_w, xx = rem - yy * res_w;
+            const float2 lo = *reinterpret_cast<const float2*>(res + (size_t)plane * (OHW >> 2) + (yy >> 1) * (res_w >> 1) + (xx >> 1));
+            r = make_float4(lo.x, lo.x, lo.y, lo.y);
+        } else {
+            r = reinterpret_cast<const float4*>(res)[i];
+        }
         a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
     }
     if (act != SEMPYR_ACT_NONE) {
@@ -992,7 +1006,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_tail_kernel(const float* __
                                                                  const float* __restrict__ bias, int splits,
                                                                  long long slab_stride, int begin, int total, int OHW, int OC,
                                                                  int act, float slope, const float* __restrict__ scale,
-                                                                 const float* __restrict__ res)
+                                                                 const float* __restrict__ res, int res_w)
 {
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -1000,7 +1014,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_tail_kernel(const float* __
     for (int k = 1; k < splits; ++k) a += slabs[(size_t)k * slab_stride + i];
     if (scale) a *= scale[(i / OHW) % OC];
     if (bias) a += bias[(i / OHW) % OC];
-    if (res) a += res[i];
+    if (res) {
+        if (res_w > 0) {
+            const int plane = i / OHW, rem = i - plane * OHW;
+            const int yy = rem / res_w, xx = rem - yy * res_w;
+            a += res[(size_t)plane * (OHW >> 2) + (yy >> 1) * (res_w >> 1) + (xx >> 1)];
+        } else {
+            a += res[i];
+        }
+    }
     out[i] = act_apply(a, act, slope);
 }
 
@@ -1721,16 +1743,17 @@ extern "C" int sempyr_conv2d_pack_weights_many(const sempyr_pack_item* items, in
 
 static int run_splitk_reduce(const float* slabs, float* out, const float* bias, int splits, long long numel,
                              int OHW, int OC, int act, float slope, hipStream_t st,
-                             const float* scale = nullptr, const float* res = nullptr)
+                             const float* scale = nullptr, const float* res = nullptr, int res_w = 0)
 {
     // float4 path only when every slab start (k * numel floats) stays 16-byte aligned
-    if (numel % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)res) & 15) == 0) {
+    const bool res_ok = res_w > 0 ? (res_w % 4 == 0 && ((uintptr_t)res & 7) == 0) : (((uintptr_t)res & 15) == 0);
+    if (numel % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0 && res_ok) {
         const int total4 = (int)(numel / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st,
-                           slabs, out, bias, splits, numel, total4, OHW, OC, act, slope, scale, res);
+                           slabs, out, bias, splits, numel, total4, OHW, OC, act, slope, scale, res, res_w);
     } else {
         hipLaunchKernelGGL(splitk_reduce_tail_kernel, dim3(ceil_div(numel, 256)), dim3(256), 0, st,
-                           slabs, out, bias, splits, numel, 0, (int)numel, OHW, OC, act, slope, scale, res);
+                           slabs, out, bias, splits, numel, 0, (int)numel, OHW, OC, act, slope, scale, res, res_w);
     }
     SEMPYR_CHECK_LAUNCH();
     return 0;
@@ -1738,7 +1761,7 @@ static int run_splitk_reduce(const float* slabs, float* out, const float* bias, 
 
 extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
                                  const int32_t* ktab, const float* bias, const float* scale, const float* res,
-                                 int act, float slope, float* y,
+                                 int res_half, int act, float slope, float* y,
                                  float* y_pooled, void* ws, size_t ws_bytes, void* stream)
 {
     sempyr_conv_plan pl;
@@ -1765,7 +1788,8 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = (int)(pl.wpack_floats * 4);
     if ((scale || res) && (d->Cout <= 4 || y_pooled))
         SEMPYR_FAIL("conv fwd: the scale / residual epilogue is not available for RGB heads or pooled outputs");
-    if (splits == 1) { p.Out = y; p.bias = bias; p.scale = scale; p.res = res; p.slab_stride = 0; p.act = act; p.slope = slope; }
+    if (res_half && (!res || ((pl.Ho | pl.Wo) & 1))) SEMPYR_FAIL("conv fwd: a half-resolution residual needs even output height and width");
+    if (splits == 1) { p.Out = y; p.bias = bias; p.scale = scale; p.res = res; p.res_half = res_half ? 1 : 0; p.slab_stride = 0; p.act = act; p.slope = slope; }
     else { p.Out = (float*)ws; p.bias = nullptr; p.slab_stride = out_numel; }
     if (y_pooled && ((pl.Ho | pl.Wo) & 1)) SEMPYR_FAIL("conv fwd: pooled output needs even output height and width");
     if (y_pooled && act == SEMPYR_ACT_TANH) SEMPYR_FAIL("conv fwd: pooled output is defined for ReLU-family activations");
@@ -1780,7 +1804,7 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     }
     if (rc) return rc;
     if (splits > 1)
-        if ((rc = run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st, scale, res))) return rc;
+        if ((rc = run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st, scale, res, res_half ? pl.Wo : 0))) return rc;
     if (y_pooled && !fused_pool)
         return sempyr_pool2_down(y, nullptr, y_pooled, d->B * d->Cout, pl.Ho, pl.Wo, 0.25f, SEMPYR_ACT_NONE, 0.f, stream);
     return 0;

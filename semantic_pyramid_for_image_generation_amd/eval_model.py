@@ -29,16 +29,20 @@ def synthesize_batch(generator, classifier, images, normalizer_clf, num_levels=4
     with torch.no_grad():
         generator.eval()
         _, features = classifier(normalizer_clf(images))
-        masks = [torch.ones(f.shape, device=device) for f in features]
+        # eval-mode BatchNorm: samples are independent, so the num_noises generator calls of the reference loop run as
+        # ONE batch of num_noises*B (same images in the same order, 4x fewer and 4x fuller launches).  The batched masks
+        # (all ones), the batched taps and the batched zero taps of the other levels (eval_model.py:72-75) are the same for
+        # every level: they are built once per source batch, not once per level.
+        rep = lambda t: t.repeat(num_noises, 1, 1, 1)
+        masks = [torch.ones((num_noises * f.shape[0],) + tuple(f.shape[1:]), device=device) for f in features]
+        taps = [rep(f) for f in features]
+        zeros = [torch.zeros_like(t) for t in taps]
         out = {}
         for level in range(1, num_levels + 1):
-            feats = one_level(features, level)
+            feats = [taps[i] if i == level else zeros[i] for i in range(len(features))]
             zs = [noises[level - 1][i] if noises is not None else torch.randn(B, 128, 1, 1, device=device)
                   for i in range(num_noises)]
-            # eval-mode BatchNorm: samples are independent, so the num_noises generator calls of the reference loop run as
-            # ONE batch of num_noises*B (same images in the same order, 4x fewer and 4x fuller launches)
-            rep = lambda t: t.repeat(num_noises, 1, 1, 1)
-            out[level] = generator(torch.cat(zs), [rep(f) for f in feats], [rep(m) for m in masks])
+            out[level] = generator(torch.cat(zs), feats, masks)
     return out
 
 

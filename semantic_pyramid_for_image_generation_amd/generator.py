@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from . import ops
 from .blocks import (init_weights, run_conv, run_conv_norm, run_conv_norm_act,  # noqa: F401  (init_weights re-exported)
-                     run_norm_add_norm_act, tail_takes_half_res, _single)
+                     run_norm_add_norm_act, tail_takes_half_res, fuses_conv_norm, _single)
 
 
 class ConvBlock(nn.Module):
@@ -43,9 +43,15 @@ class ResidualBlock(nn.Module):
         up = self.need_upsample           # both consumers gather through the x2 upsample; no 4x tensor is written
         if not (self.conv_block2.block[1].training or self.skip_block.block[1].training):
             # eval mode (eval_model.py / `sample`): each BatchNorm folds into its conv, the add + ReLU into the last one
-            residual = run_conv_norm(self.skip_block.block[0], self.skip_block.block[1], x, upsample=up)
+            # (the 1x1 skip conv commutes with the nearest upsample: it runs at the low resolution and the last conv's
+            # epilogue reads it through the upsample)
+            sk = self.skip_block.block[0]
+            half = up and _single(sk.kernel_size) == 1 and _single(sk.stride) == 1 and _single(sk.padding) == 0 and \
+                fuses_conv_norm(self.conv_block2.block[0], self.conv_block2.block[1])
+            residual = run_conv_norm(sk, self.skip_block.block[1], x, upsample=up and not half)
             h = self.conv_block1(x, upsample=up)
-            return run_conv_norm(self.conv_block2.block[0], self.conv_block2.block[1], h, ops.ACT_RELU, res=residual)
+            return run_conv_norm(self.conv_block2.block[0], self.conv_block2.block[1], h, ops.ACT_RELU, res=residual,
+                                 res_half=half)
         # the 1x1 skip convolution commutes with the nearest upsample: it runs on the low-resolution map (a quarter of the
         # work and of the tensor), its BatchNorm statistics are those of the upsampled map, and the tail pass reads it
         # through the upsample

@@ -396,14 +396,14 @@ def _workspace(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None, scale_ptr=0, res=None):
+def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None, scale_ptr=0, res=None, res_half=False):
     """`bias` is a tensor or a raw device address (the shift row of cached BatchNorm coefficients)."""
     mp = plan.mode(CONV_FWD)
     wp = _packed_weights(plan, w, CONV_FWD)
     y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device)
     ws = _workspace(mp.ws_bytes, x.device)
     check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(),
-                              bias if isinstance(bias, int) else _p(bias), scale_ptr, _p(res), act_kind, slope,
+                              bias if isinstance(bias, int) else _p(bias), scale_ptr, _p(res), 1 if res_half else 0, act_kind, slope,
                               y.data_ptr(), _p(pooled), _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
     return y
 
@@ -850,26 +850,29 @@ class _ConvBnEval(Function):
     the residual add and the activation run in the convolution's epilogue.  `coeffs` are constants, as in _AffineRowAct."""
 
     @staticmethod
-    def forward(ctx, x, w, res, plan, coeffs, act_kind, slope):
+    def forward(ctx, x, w, res, plan, coeffs, act_kind, slope, res_half=False):
         x = _req(x, "conv input"); w = _req(w, "conv weight")
         if res is not None:
             res = _req(res, "residual")
-            if tuple(res.shape) != (plan.B, plan.Cout, plan.Ho, plan.Wo):
-                raise _lib.SempyrError("conv + BatchNorm: the residual must have the output's shape")
+            want = (plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2) if res_half else (plan.B, plan.Cout, plan.Ho, plan.Wo)
+            if tuple(res.shape) != want or (res_half and (plan.Ho % 2 or plan.Wo % 2)):
+                raise _lib.SempyrError("conv + BatchNorm: the residual must have the output's shape (or half of it)")
+        elif res_half:
+            raise _lib.SempyrError("conv + BatchNorm: res_half without a residual")
         rows = plan.B * plan.Cout
         if coeffs.numel() != 2 * rows:
             raise _lib.SempyrError("conv + BatchNorm: coefficient table does not match the output")
-        y = _raw_conv_fwd(plan, x, w, coeffs.data_ptr() + 4 * rows, act_kind, slope, None, coeffs.data_ptr(), res)
+        y = _raw_conv_fwd(plan, x, w, coeffs.data_ptr() + 4 * rows, act_kind, slope, None, coeffs.data_ptr(), res, res_half)
         ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None, coeffs)
         ctx.plan = plan
-        ctx.cfg = (act_kind, slope, res is not None)
+        ctx.cfg = (act_kind, slope, res is not None, res_half)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y, coeffs = ctx.saved_tensors
         plan = ctx.plan
-        act_kind, slope, has_res = ctx.cfg
+        act_kind, slope, has_res, res_half = ctx.cfg
         if torch.is_grad_enabled() and gy.requires_grad:
             raise NotImplementedError("double backward through eval-mode BatchNorm is not part of the hot path")
         gy = _req(gy, "grad")
@@ -878,9 +881,11 @@ class _ConvBnEval(Function):
         gres = torch.empty_like(gy) if (has_res and ctx.needs_input_grad[2]) else None
         g = torch.empty_like(gy) if (want_x or want_w) else None
         if g is None and gres is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         check(L.sempyr_affine_act_bwd(gy.data_ptr(), _p(y), coeffs.data_ptr(), _p(g), _p(gres), rows, HW, act_kind, slope,
                                       _stream()), "sempyr_affine_act_bwd")
+        if gres is not None and res_half:
+            gres = _apply(_Pool2Down, gres, 1.0)          # adjoint of the nearest upsample the residual was read through
         gx = gw = None
         if want_w:
             if _can_async(w, None, True, False):
@@ -889,11 +894,11 @@ class _ConvBnEval(Function):
                 gw = _apply(_ConvWgrad, g, x, plan)
         if want_x:
             gx = _conv_input_grad(g, w, plan)
-        return gx, gw, gres, None, None, None, None
+        return gx, gw, gres, None, None, None, None, None
 
 
 def conv_bn_eval_act(x, w, gamma, beta, running_mean, running_var, eps=1e-5, stride=1, padding=0, upsample=False, res=None,
-                     act_kind=ACT_NONE, slope=0.0):
+                     act_kind=ACT_NONE, slope=0.0, res_half=False):
     """Bias-free nn.Conv2d followed by an eval-mode nn.BatchNorm2d, an optional residual add and an activation — the
     BasicBlock pattern of the frozen ResNet18 classifier (classifier.py:34-40) and the generator's ConvBlock / ResidualBlock
     under .eval() (generator.py:27-29,54-57 from eval_model.py) — as a single convolution launch."""
@@ -905,7 +910,7 @@ def conv_bn_eval_act(x, w, gamma, beta, running_mean, running_var, eps=1e-5, str
         raise _lib.SempyrError(f"BatchNorm2d over {gamma.numel()} channels after a conv with {Cout} outputs")
     plan = get_plan((B, Cin, H, W, Cout, kh, kw, stride, padding, 1 if upsample else 0), x.device)
     coeffs = _bn_eval_cached(gamma, beta, running_mean, running_var, eps, B)
-    return _apply(_ConvBnEval, x, w, res, plan, coeffs, act_kind, slope)
+    return _apply(_ConvBnEval, x, w, res, plan, coeffs, act_kind, slope, res_half)
 
 
 # ------------------------------------------------------------------------------------------------

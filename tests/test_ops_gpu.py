@@ -301,7 +301,7 @@ def test_bn_eval_act_residual(dev):
 @pytest.mark.parametrize("case", [(2, 64, 32, 32, 64, 3, 1, 1, 0), (2, 64, 16, 16, 64, 3, 1, 1, 1), (2, 64, 16, 16, 128, 3, 2, 1, 0),
                                   (2, 64, 16, 16, 128, 1, 2, 0, 0), (1, 512, 8, 8, 512, 3, 1, 1, 0), (1, 5, 9, 11, 7, 3, 1, 1, 0),
                                   (2, 3, 64, 64, 64, 7, 2, 3, 0), (2, 64, 16, 16, 64, 1, 1, 0, 1)])
-@pytest.mark.parametrize("with_res,act", [(True, 'relu'), (False, 'relu'), (False, 'none')])
+@pytest.mark.parametrize("with_res,act", [(True, 'relu'), (False, 'relu'), (False, 'none'), ('half', 'relu')])
 def test_conv_bn_eval_fused(dev, case, with_res, act):
     ops = _ops()
     B, Cin, H, W, Cout, k, s, p, ups = case
@@ -313,17 +313,21 @@ def test_conv_bn_eval_fused(dev, case, with_res, act):
     xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
     xin = F.interpolate(xr, scale_factor=2, mode='nearest') if ups else xr
     pre = F.batch_norm(F.conv2d(xin, wr, None, s, p), rm, rv, gam, bet, False, 0.1, 1e-5)
-    res = torch.randn(pre.shape, generator=g) if with_res else None
+    half = with_res == 'half'           # the residual is given at half resolution and read through a nearest upsample
+    if half and (pre.shape[2] % 2 or pre.shape[3] % 2):
+        pytest.skip("half-resolution residual needs even output height and width")
+    rshape = (pre.shape[0], pre.shape[1], pre.shape[2] // 2, pre.shape[3] // 2) if half else pre.shape
+    res = torch.randn(rshape, generator=g) if with_res else None
     rr = res.clone().requires_grad_(True) if with_res else None
     if with_res:
-        pre = pre + rr
+        pre = pre + (F.interpolate(rr, scale_factor=2, mode='nearest') if half else rr)
     yr = F.relu(pre) if act == 'relu' else pre
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy)
     xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
     rd = res.to(dev).requires_grad_(True) if with_res else None
     y = ops.conv_bn_eval_act(xd, wd, gam.to(dev), bet.to(dev), rm.to(dev), rv.to(dev), 1e-5, s, p, upsample=bool(ups), res=rd,
-                             act_kind=ops.ACT_RELU if act == 'relu' else ops.ACT_NONE)
+                             act_kind=ops.ACT_RELU if act == 'relu' else ops.ACT_NONE, res_half=half)
     assert y.shape == yr.shape
     y.backward(gy.to(dev))
     ops.join_side_streams()
@@ -336,7 +340,7 @@ def test_conv_bn_eval_fused(dev, case, with_res, act):
     # the same call without autograd (eval_model.py runs under no_grad)
     with torch.no_grad():
         y2 = ops.conv_bn_eval_act(xd, wd, gam.to(dev), bet.to(dev), rm.to(dev), rv.to(dev), 1e-5, s, p, upsample=bool(ups),
-                                  res=rd, act_kind=ops.ACT_RELU if act == 'relu' else ops.ACT_NONE)
+                                  res=rd, act_kind=ops.ACT_RELU if act == 'relu' else ops.ACT_NONE, res_half=half)
     assert torch.equal(y2, y)
 
 
