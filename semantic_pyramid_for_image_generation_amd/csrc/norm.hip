@@ -25,6 +25,13 @@ __device__ __forceinline__ float act_deriv(float y, int act, float slope) {
 // TPR = 256: the whole block. Result valid in all participating threads.
 template <int TPR, int NS>
 __device__ __forceinline__ void row_reduce(float (&v)[NS], float* sh) {
+    if constexpr (TPR < 64) {                  // several rows per wave: reduce inside each aligned group of TPR lanes
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o, 64);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) v[i] = wave_sum(v[i]);
     if (TPR == 256) {
@@ -849,6 +856,8 @@ extern "C" int sempyr_norm_fwd(int kind, const float* x, int N, int C, int HW, f
         bool done = false;
         if (vec && HW >= 2048 && HW % 1024 == 0) done = launch_instnorm_fwd_reg<256>(HW / 1024, dim3(rows), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
         else if (vec && HW < 2048 && HW % 256 == 0) done = launch_instnorm_fwd_reg<64>(HW / 256, dim3(ceil_div(rows, 4)), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
+        else if (vec && HW == 64) done = launch_instnorm_fwd_reg<16>(1, dim3(ceil_div(rows, 16)), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
+        else if (vec && HW == 16) done = launch_instnorm_fwd_reg<4>(1, dim3(ceil_div(rows, 64)), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
         if (done) { SEMPYR_CHECK_LAUNCH(); return 0; }
         if (HW >= 2048) hipLaunchKernelGGL(instnorm_fwd_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, C, HW, vec, eps, gamma, beta, act, slope, y, rowbuf);
         else hipLaunchKernelGGL(instnorm_fwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, C, HW, vec, eps, gamma, beta, act, slope, y, rowbuf);
@@ -888,6 +897,8 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
         bool done = false;
         if (vec && HW >= 2048 && HW % 1024 == 0) done = launch_instnorm_bwd_reg<256>(HW / 1024, dim3(rows), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
         else if (vec && HW < 2048 && HW % 256 == 0) done = launch_instnorm_bwd_reg<64>(HW / 256, dim3(ceil_div(rows, 4)), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
+        else if (vec && HW == 64) done = launch_instnorm_bwd_reg<16>(1, dim3(ceil_div(rows, 16)), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
+        else if (vec && HW == 16) done = launch_instnorm_bwd_reg<4>(1, dim3(ceil_div(rows, 64)), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
         if (!done) {
         if (HW >= 2048) hipLaunchKernelGGL(instnorm_bwd_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);
         else hipLaunchKernelGGL(instnorm_bwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);

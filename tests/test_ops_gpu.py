@@ -185,7 +185,7 @@ def _torch_norm(kind, x, gam, bet, eps=1e-5):
 
 
 @pytest.mark.parametrize("kind", NORM_KINDS)
-@pytest.mark.parametrize("shape", [(3, 8, 4, 4), (2, 5, 7, 9), (2, 4, 64, 64), (2, 4, 16, 16), (2, 3, 32, 32), (1, 2, 64, 32)])
+@pytest.mark.parametrize("shape", [(3, 8, 4, 4), (2, 5, 7, 9), (2, 4, 64, 64), (2, 4, 16, 16), (2, 3, 32, 32), (1, 2, 64, 32), (3, 6, 8, 8), (5, 30, 4, 4)])
 @pytest.mark.parametrize("act", ['none', 'lrelu'])
 def test_norm_fwd_bwd_bwdbwd(dev, kind, shape, act):
     ops = _ops()
