@@ -1108,11 +1108,14 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ALU: padding M = 3 to a 32-row MFMA tile wastes 10x the matrix work (0.55 ms, 6.6 TFLOP/s).  A workgroup owns RGBW_ROWS image
 // rows of one sample and RGBW_CG input channels; a thread owns one pixel column, walks down its rows with a rolling 3x3
 // window per channel (3 new loads per channel and row) and keeps NM x 9 x RGBW_CG accumulators; the workgroup's sums go
-// to `part` [strip][C][NM*9] and rgbw_reduce_kernel adds the strips in a fixed order.
-constexpr int RGBW_ROWS = 32, RGBW_CG = 4;
-template <int NM>
+// to `part` [strip][C][NM*9] and rgbw_reduce_kernel adds the strips in a fixed order.  Measured on 64 -> 3 at 256x256,
+// batch 16: the per-workgroup reduction of the accumulators is the expensive part, so long strips win (rows 32 / 4 channels
+// 291 us, 128 / 2 channels 146 us, 8 / 4 channels 627 us; MFMA path 577 us).
+inline int rgbw_rows();
+inline int rgbw_cg();
+template <int NM, int RGBW_CG>
 __global__ __launch_bounds__(256) void rgb_wgrad3x3_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                           int C, int H, int W, float* __restrict__ part)
+                                                           int C, int H, int W, int RGBW_ROWS, float* __restrict__ part)
 {
     __shared__ float sh[4][NM * 9 * RGBW_CG];
     const int nstrip_img = (H + RGBW_ROWS - 1) / RGBW_ROWS;
@@ -1555,11 +1558,13 @@ int launch_cfg(int cfg, const IgemmParams& p, int splits, bool uniform_tap, hipS
 } // namespace
 
 namespace {
-// Shapes served by rgb_wgrad3x3_kernel
+// Shapes served by rgb_wgrad3x3_kernel; rows per strip / channels per workgroup (SEMPYR_RGBW_ROWS / _CG: tuning aids)
+inline int rgbw_rows() { static const int v = env_int("SEMPYR_RGBW_ROWS", 128); return v < 1 ? 1 : v; }
+inline int rgbw_cg() { static const int v = env_int("SEMPYR_RGBW_CG", 2); return v == 4 ? 4 : 2; }
 inline bool rgb_wgrad_ok(const sempyr_conv_desc* d) {
     static const int enabled = env_int("SEMPYR_RGB_WGRAD", 1);
     return enabled && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->ups == 0 && d->Cout <= 4 &&
-           d->Cin % RGBW_CG == 0 && d->Win <= 256 && 256 % d->Win == 0;
+           d->Cin % rgbw_cg() == 0 && d->Win <= 256 && 256 % d->Win == 0;
 }
 }  // namespace
 
@@ -1637,7 +1642,7 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(Nn, bn), plan->Kpad[0] / BK, plan->splits[0], cps, target_blocks_wgrad());
         plan->workspace_bytes = (long long)plan->splits[0] * d->Cout * Nn * 4;
         if (rgb_wgrad_ok(d)) {
-            const long long need = (long long)d->B * ceil_div(d->Hin, RGBW_ROWS) * d->Cin * d->Cout * 9 * 4;
+            const long long need = (long long)d->B * ceil_div(d->Hin, rgbw_rows()) * d->Cin * d->Cout * 9 * 4;
             if (need > plan->workspace_bytes) plan->workspace_bytes = need;
         }
     }
@@ -1892,6 +1897,7 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     const int T = d->kh * d->kw;
     const int Nn = pl.tab_entries;
     if (rgb_wgrad_ok(d)) {
+        const int RGBW_ROWS = rgbw_rows(), RGBW_CG = rgbw_cg();
         const int nstrips = d->B * ceil_div(d->Hin, RGBW_ROWS);
         dim3 grid((unsigned)(nstrips * (d->Cin / RGBW_CG)));
         float* part = (float*)ws;
@@ -1907,12 +1913,16 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
             }
         }
         if (e0) (void)hipEventRecord(e0, st);
+#define SEMPYR_RGBW(NM) do { \
+            if (RGBW_CG == 2) hipLaunchKernelGGL((rgb_wgrad3x3_kernel<NM, 2>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, RGBW_ROWS, part); \
+            else hipLaunchKernelGGL((rgb_wgrad3x3_kernel<NM, 4>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, RGBW_ROWS, part); } while (0)
         switch (d->Cout) {
-            case 1: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<1>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
-            case 2: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<2>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
-            case 3: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<3>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
-            default: hipLaunchKernelGGL((rgb_wgrad3x3_kernel<4>), grid, dim3(256), 0, st, gy, x, d->Cin, d->Hin, d->Win, part); break;
+            case 1: SEMPYR_RGBW(1); break;
+            case 2: SEMPYR_RGBW(2); break;
+            case 3: SEMPYR_RGBW(3); break;
+            default: SEMPYR_RGBW(4); break;
         }
+#undef SEMPYR_RGBW
         if (e1) (void)hipEventRecord(e1, st);
         SEMPYR_CHECK_LAUNCH();
         hipLaunchKernelGGL(rgbw_reduce_kernel, dim3(ceil_div(d->Cin * d->Cout * 9, 256)), dim3(256), 0, st,
