@@ -7,7 +7,7 @@ for f in sorted(glob.glob(f'gpurun_out/pmc_{tag}/p*_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
         if 'igemm_kernel' in n or 'patch3x3' in n or 'rgb3x3' in n:
-            short = n.split('::')[-1].split('(')[0]
+            short = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(IgemmParams')[0]
             vals[short][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
 for k, c in vals.items():
