@@ -143,9 +143,15 @@ def main():
                 tm.setMasksPart2(masks, device, L)
             fake = tm.fake_for_discriminator(G, B, features, masks)
             pf.hand_over(images_d, features, masks, fake)
+            z_g = fake_g = None
+            if it[0] % 5 == 1 and pf.on:          # the generator step's own forward does not depend on the critic step either
+                z_g = torch.randn(B, 128, 1, 1, device=device)
+                fake_g = tm.fake_for_generator(G, features, masks, z_g)
+                pf.hand_over(z_g, fake_g)
         tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks, fake_images=fake)
         if it[0] % 5 == 1:
-            tm.train_generator(G, D, g_loss_fn, g_opt, B, features, crit, L, C, normalizer_clf, crit, crit, masks, train_type)
+            tm.train_generator(G, D, g_loss_fn, g_opt, B, features, crit, L, C, normalizer_clf, crit, crit, masks, train_type,
+                               z=z_g, fake_images=fake_g)
 
     def cycle():
         for _ in range(5):

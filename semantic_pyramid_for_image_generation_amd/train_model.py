@@ -159,17 +159,22 @@ class _frozen:
 
 def train_generator(generator, discriminator, generator_loss_fn, generator_optimizer, batch_size, features, criterion_features,
                     features_to_train, classifier, normalizer_clf, criterion_diversity_n, criterion_diversity_d, masks,
-                    train_type, epsilon=10e-4, z=None, z2=None):
+                    train_type, epsilon=10e-4, z=None, z2=None, fake_images=None):
     """One generator step (reference :83-119).  `z` / `z2` may be injected (parity tests); by default they are
-    drawn on the device generator as in the reference."""
+    drawn on the device generator as in the reference.  `fake_images`: the step's own forward `generator(z, features,
+    masks)` WITH its autograd graph, computed ahead by the caller (`fake_for_generator` inside a `prefetch` block: that
+    forward does not depend on the critic step in front of it); `z` must then be the noise it was made from."""
     device = features[1].device
     _ensure_train(generator)
     _ensure_train(discriminator)
+    if fake_images is not None and z is None:
+        raise ValueError("train_generator: fake_images needs the z it was generated from")
     if z is None:
         z = torch.randn(batch_size, 128, 1, 1, device=device)
 
     with _frozen(discriminator, classifier):
-        fake_images = generator(z, features, masks)
+        if fake_images is None:
+            fake_images = generator(z, features, masks)
         two_stream = ops.TWO_STREAM_GENERATOR and fake_images.is_cuda
         if two_stream:
             # the critic branch and the classifier-feature branch only share fake_images: two streams (forward and, through
@@ -259,6 +264,13 @@ class prefetch:
     @property
     def consumers(self):
         return [self.main] + ops.consumer_streams(self.device)[1:]
+
+
+def fake_for_generator(generator, features, masks, z):
+    """The generator step's own forward (reference train_model.py:93), with its autograd graph, for a caller that runs it
+    ahead of the critic step inside a `prefetch` block; pass the result and `z` to train_generator."""
+    _ensure_train(generator)
+    return generator(z, features, masks)
 
 
 def fake_for_discriminator(generator, batch_size, features, masks, z=None):
@@ -519,6 +531,12 @@ def _main():
                 setMasksPart2(masks, device, features_to_train)
             fake_images = fake_for_discriminator(generator, images.shape[0], features, masks)
             pf.hand_over(images, images_discriminator, features, masks, fake_images)
+            z_g = fake_g = None
+            if iterations % args.discriminator_steps == 1 and pf.on:
+                # this iteration ends with a generator step: its forward does not depend on the critic step either
+                z_g = torch.randn(images.shape[0], 128, 1, 1, device=device)
+                fake_g = fake_for_generator(generator, features, masks, z_g)
+                pf.hand_over(z_g, fake_g)
             pf.__exit__(None, None, None)
             discriminator_loss_dict = train_discriminator(generator, discriminator, criterion_discriminator,
                                                           discriminator_optimizer, images_discriminator, features, masks,
@@ -530,7 +548,8 @@ def _main():
             if iterations % args.discriminator_steps == 1:
                 generator_loss_dict = train_generator(generator, discriminator, criterion_generator, generator_optimizer,
                                                       images.shape[0], features, criterion_features, features_to_train, classifier,
-                                                      normalizer_clf, criterion_diversity_n, criterion_diversity_d, masks, train_type)
+                                                      normalizer_clf, criterion_diversity_n, criterion_diversity_d, masks, train_type,
+                                                      z=z_g, fake_images=fake_g)
                 for k, v in generator_loss_dict.items():
                     pending.append(('G/%s' % k, iterations // 5 + 1, v.detach()))
                     if iterations % 30 == 1:

@@ -295,12 +295,17 @@ def test_prefetched_iterations_match_in_place(dev):
                     random.setstate(state)
                     fake = tm.fake_for_discriminator(G, imgs.shape[0], features, masks)
                     pf.hand_over(images_d, features, masks, fake)
+                    zg = z[:imgs.shape[0]].to(dev)
+                    fake_g = None
+                    if it == 1 and prefetch_on:         # the generator step's own forward, ahead of the critic step
+                        fake_g = tm.fake_for_generator(G, features, masks, zg)
+                        pf.hand_over(zg, fake_g)
                 out = tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks, fake_images=fake,
                                              alpha=alpha[:imgs.shape[0]].to(dev))
                 losses += [out['d_loss'].detach().clone(), out['gp'].detach().clone()]
                 if it == 1:
                     og = tm.train_generator(G, D, g_loss_fn, g_opt, imgs.shape[0], features, crit, L, C, norm_clf, crit, crit,
-                                            masks, [2])
+                                            masks, [2], z=zg, fake_images=fake_g)
                     losses.append(og['total_loss'].detach().clone())
             torch.cuda.synchronize()
             return ([float(v) for v in losses], {k: v.detach().clone() for k, v in D.state_dict().items()},
