@@ -239,9 +239,9 @@ class prefetch:
         if self.on:
             self.main = torch.cuda.current_stream(self.device)
             self.stream = ops.prefetch_stream(self.device)
-            ev = _GEN_UPDATED.get(id(self.generator))
-            if ev is not None:
-                self.stream.wait_event(ev)
+            # (the generator's last update is waited for where the generator is first used — fake_for_discriminator /
+            # fake_for_generator — so the classifier taps and masks of the iteration after a generator step overlap that
+            # step's backward as well)
             self.ctx = torch.cuda.stream(self.stream)
             self.ctx.__enter__()
         return self
@@ -266,10 +266,19 @@ class prefetch:
         return [self.main] + ops.consumer_streams(self.device)[1:]
 
 
+def _wait_for_generator_update(generator, device):
+    """Order the current stream behind the generator's last optimizer step (it may have been issued on another stream)."""
+    if device.type == 'cuda':
+        ev = _GEN_UPDATED.get(id(generator))
+        if ev is not None:
+            torch.cuda.current_stream(device).wait_event(ev)
+
+
 def fake_for_generator(generator, features, masks, z):
     """The generator step's own forward (reference train_model.py:93), with its autograd graph, for a caller that runs it
     ahead of the critic step inside a `prefetch` block; pass the result and `z` to train_generator."""
     _ensure_train(generator)
+    _wait_for_generator_update(generator, features[1].device)
     return generator(z, features, masks)
 
 
@@ -279,6 +288,7 @@ def fake_for_discriminator(generator, batch_size, features, masks, z=None):
     _ensure_train(generator)
     if z is None:
         z = _cpu_randn_to(device, batch_size, 128, 1, 1)
+    _wait_for_generator_update(generator, device)
     with torch.no_grad():
         return generator(z, features, masks)
 
