@@ -97,12 +97,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
+    ap.add_argument('--loop-mode', default=os.environ.get('SEMPYR_LOOP_MODE', 'eager'), choices=['eager', 'replay', 'hipgraph'],
+                    help='eager: the body is issued from Python on four streams; replay: captured once per variant and re-issued by '
+                         'sempyr_replay_launch; hipgraph: captured and replayed by hipGraphLaunch')
     a = ap.parse_args()
     if os.environ.get('SEMPYR_BENCH_TRACE'):          # debugging aid: where is every thread after N seconds?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['SEMPYR_BENCH_TRACE']), exit=True)
 
-    from semantic_pyramid_for_image_generation_amd import _lib, eval_model, ops, optim, parallel
+    from semantic_pyramid_for_image_generation_amd import _lib, eval_model, loop, ops, optim, parallel
     from semantic_pyramid_for_image_generation_amd import train_model as tm
     device = parallel.init_device()
     rank, world = parallel.rank(), parallel.world_size()
@@ -112,50 +115,25 @@ def main():
     G, D, C = build_models(device, a.gen_type, a.discriminator_norm)
     parallel.broadcast_module(G); parallel.broadcast_module(D); parallel.broadcast_module(C)
     tm.args = Namespace(use_diversity_loss=a.use_diversity_loss, gradient_penalty_weight=10.0)
-    d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
-    crit = tm.L1Loss()
-    g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
+    d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
     normalizer_clf = tm.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
-    normalizer_d = tm.Normalize([0.5, 0.5, 0.5], [0.5, 0.5, 0.5])
 
     B = a.batch
     gen = torch.Generator().manual_seed(1234 + rank)
     pool = [torch.rand(B, 3, 256, 256, generator=gen).to(device) for _ in range(5)]    # resident in HBM
     torch.manual_seed(100 + rank)          # rank-distinct z / alpha
     random.seed(0)                         # identical layer / crop draws on every rank
+    # the loop body of train_model.py:300-349 (draws, classifier taps, masks, critic step, generator step every 5th
+    # iteration) -- the object train_model._main drives; `--loop-mode` picks how the recorded body is issued
+    lp = loop.TrainLoop(G, D, C, g_opt, d_opt, B, device, use_graphs=(a.loop_mode != 'eager'),
+                        executor='hip' if a.loop_mode == 'hipgraph' else 'own')
     it = [0]
-
-    def loop_iteration():
-        """body of train_model.py:300-349 without logging / checkpoint I/O"""
-        it[0] += 1
-        train_type = random.choices([1, 2], [0.6, 0.4])
-        images = pool[it[0] % len(pool)]
-        with tm.prefetch(G, device) as pf:       # independent of the previous critic step: overlaps its backward
-            images_d = normalizer_d(images)
-            with torch.no_grad():
-                _, features = C(normalizer_clf(images))
-            L = random.randint(1, len(features) - 2)
-            masks = [f.clone() for f in features]
-            if train_type == 1:
-                tm.setMasksPart1(masks, device, L)
-            else:
-                tm.setMasksPart2(masks, device, L)
-            fake = tm.fake_for_discriminator(G, B, features, masks)
-            pf.hand_over(images_d, features, masks, fake)
-            z_g = fake_g = None
-            if it[0] % 5 == 1 and pf.on:          # the generator step's own forward does not depend on the critic step either
-                z_g = torch.randn(B, 128, 1, 1, device=device)
-                fake_g = tm.fake_for_generator(G, features, masks, z_g)
-                pf.hand_over(z_g, fake_g)
-        tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks, fake_images=fake)
-        if it[0] % 5 == 1:
-            tm.train_generator(G, D, g_loss_fn, g_opt, B, features, crit, L, C, normalizer_clf, crit, crit, masks, train_type,
-                               z=z_g, fake_images=fake_g)
 
     def cycle():
         for _ in range(5):
-            loop_iteration()
+            it[0] += 1
+            lp.iteration(pool[it[0] % len(pool)])
 
     def barrier():
         if world > 1:
@@ -163,7 +141,8 @@ def main():
         torch.cuda.synchronize()
 
     # first use of every shape (launch plans, gather tables, packed weights, allocator pools for all four feature levels and
-    # both mask types) happens here, before the W warmup steps the contract asks for
+    # both mask types) and the captures happen here, before the W warmup steps the contract asks for
+    lp.prepare()
     for _ in range(2):
         cycle()
     for _ in range(a.warmup):
@@ -188,6 +167,7 @@ def main():
         # single-stream for this pass: a kernel's event-to-event time is only its own duration when nothing else shares the GPU
         saved = (ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH)
         ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = ops.PREFETCH = False
+        saved_graphs, lp.use_graphs = lp.use_graphs, False          # event pairs are recorded by the launch functions: issue eagerly
         _lib.check(_lib.lib.sempyr_profile_begin(4096 * max(a.steps, 1)), "sempyr_profile_begin")
         t1 = time.perf_counter()
         for _ in range(a.steps):
@@ -196,6 +176,7 @@ def main():
         elapsed_instr = time.perf_counter() - t1
         _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
         ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH = saved
+        lp.use_graphs = saved_graphs
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if torch.distributed.get_backend() == 'gloo' else device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -235,7 +216,7 @@ def main():
             "config": {"workload": f"train_model.py cycle = 5 loop iterations (5 D steps + 1 G step), gen-type {a.gen_type}, "
                                    f"{a.discriminator_norm}, GP weight 10, batch {B}/GPU, 256x256"
                                    + (", diversity loss" if a.use_diversity_loss else ""),
-                       "iters_per_step": 5, "batch_per_gpu": B, "parallelism": f"dp{world}",
+                       "iters_per_step": 5, "batch_per_gpu": B, "parallelism": f"dp{world}", "loop_mode": a.loop_mode,
                        "weights": "seeded random init (trained blobs are not shipped)"},
         }
         if eval_ips is not None:

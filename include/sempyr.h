@@ -206,6 +206,50 @@ typedef struct sempyr_adam_tensor {
 } sempyr_adam_tensor;
 int sempyr_adam_step(const sempyr_adam_tensor* tensors, int n_tensors, int64_t step, double lr, double beta1, double beta2,
                      double eps, double grad_scale, int zero_grads, void* stream);
+/* The same step for a caller that replays the launch from a captured HIP graph (kernel arguments are frozen at capture):
+ * the two step-dependent scalars {-lr/(1-beta1^t), sqrt(1-beta2^t)} are read from device memory at run time.
+ * sempyr_adam_scalars computes them on the host exactly as sempyr_adam_step does (doubles, one rounding to fp32);
+ * hand them over with sempyr_store_words before each replay. */
+int sempyr_adam_scalars(int64_t step, double lr, double beta1, double beta2, float* out2_host);
+int sempyr_adam_step_dev(const sempyr_adam_tensor* tensors, int n_tensors, const float* step_scalars_dev, double beta1,
+                         double beta2, double eps, double grad_scale, int zero_grads, void* stream);
+/* dst_dev[0..n) = words_host[0..n) (n <= SEMPYR_STORE_MAX_WORDS), stream-ordered; the words travel in the kernel
+ * arguments, so the host array may be reused at once.  Hands the per-iteration scalars of the loop body
+ * (train_model.py:301,327 layer / crop draws, the Adam step scalars) to kernels that were captured into a graph. */
+#define SEMPYR_STORE_MAX_WORDS 48
+int sempyr_store_words(const uint32_t* words_host, int n, uint32_t* dst_dev, void* stream);
+/* The feature masks of setCroppedMask / setMasksPart1 / setMasksPart2 (train_model.py:172-209) in one launch: mask i
+ * ([rows][H][W] floats) = base_i everywhere except rows [x0,x1) x cols [y0,y1) = win_i.  spec_dev holds six int32 words
+ * per mask {bits(base), bits(win), x0, x1, y0, y1} in DEVICE memory (so a captured graph follows the per-iteration
+ * draws); `targets` is a HOST array. */
+#define SEMPYR_MASKS_MAX 6
+typedef struct sempyr_mask_target {
+    float* mask;
+    int32_t rows, H, W;
+} sempyr_mask_target;
+int sempyr_build_masks(const sempyr_mask_target* targets, int n, const int32_t* spec_dev, void* stream);
+/* dst = [src_0 | src_1 | ...] (n <= SEMPYR_CONCAT_MAX contiguous float arrays; HOST tables): the real and the fake batch
+ * as one critic batch (train_model.py:132-133 run as one pass when no layer mixes samples). */
+#define SEMPYR_CONCAT_MAX 8
+int sempyr_concat(const float* const* srcs_host, const int64_t* numels_host, int n, float* dst, void* stream);
+/* dst[0..n) = value : grad_outputs=torch.ones_like(pred) train_model.py:73 */
+int sempyr_fill_const(float* dst, float value, int64_t n, void* stream);
+/* *out = ((w_0*x_0 + w_1*x_1 + ...) * s1) * s2 on device scalars, products and sums rounded one by one, left to right:
+ * the loss arithmetic train_model.py:101-103,112,138 and :222 (`loss * (1/L) * 200`) in one launch. HOST tables. */
+#define SEMPYR_LINCOMB_MAX 6
+int sempyr_lincomb(const float* const* xs_host, const float* ws_host, int n, float s1, float s2, float* out, void* stream);
+/* dst_i = sum_k src_i[k] (assign != 0) or dst_i += sum_k src_i[k] (sources added in table order; unused slots NULL) for a
+ * HOST table of small tensors in one launch: autograd's gradient accumulation (`.backward()` train_model.py:116,142) for the
+ * norm-layer affine parameters of a whole pass.  A destination may appear once per SEMPYR_ACCUM_MAX items. */
+#define SEMPYR_ACCUM_MAX 32
+#define SEMPYR_ACCUM_SRCS 4
+typedef struct sempyr_accum_item {
+    float* dst;
+    const float* src[SEMPYR_ACCUM_SRCS];
+    int64_t numel;
+    int32_t assign;
+} sempyr_accum_item;
+int sempyr_accumulate_many(const sempyr_accum_item* items_host, int n, void* stream);
 /* out = real + alpha_row[r]*(fake-real) : sample_line train_model.py:51-55 */
 int sempyr_lerp_rows(const float* real, const float* fake, const float* alpha_row, float* out,
                      int rows, int len, void* stream);
@@ -250,6 +294,20 @@ int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int 
 int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float* out, int accumulate, float* scratch,
                        void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Replay of a captured loop body (no counterpart in the reference: its loop body, train_model.py:300-349, is issued op by
+ * op from Python).  sempyr_replay_create walks a captured hipGraph_t once (kernel / memset / 1-D device memcpy / empty
+ * nodes and their dependency edges) and lays the DAG out on up to max_streams HIP streams; sempyr_replay_launch re-issues
+ * every node with plain stream launches from native code -- stream 0 of the layout is the `stream` passed at launch, so the
+ * replay is ordered after earlier work on it and later work on it is ordered after the whole replay.  The graph must
+ * outlive the plan (its nodes own the kernel-argument copies).  One replay of a plan at a time.
+ * stats (optional, 8 int32): kernels, memsets, memcpys, empty nodes, streams used, cross-stream waits, events, edges.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sempyr_replay sempyr_replay;
+int sempyr_replay_create(void* hip_graph, int max_streams, sempyr_replay** out, int32_t* stats);
+int sempyr_replay_launch(sempyr_replay* plan, void* stream);
+int sempyr_replay_destroy(sempyr_replay* plan);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (no counterpart in the reference; used by bench.py only).  Between begin and end

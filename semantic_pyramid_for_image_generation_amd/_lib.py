@@ -43,7 +43,19 @@ class AdamTensor(ctypes.Structure):
                 ("numel", ctypes.c_int64)]
 
 
+class MaskTarget(ctypes.Structure):
+    _fields_ = [("mask", c_void_p), ("rows", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32)]
+
+
+class AccumItem(ctypes.Structure):
+    _fields_ = [("dst", c_void_p), ("src", c_void_p * 4), ("numel", ctypes.c_int64), ("assign", ctypes.c_int32)]
+
+
 ADAM_MAX_TENSORS = 64
+CONCAT_MAX = 8
+LINCOMB_MAX = 6
+STORE_MAX_WORDS = 48
+MASKS_MAX = 6
 
 _P = c_void_p  # every device / host pointer is passed as an integer address
 _DESC = ctypes.POINTER(ConvDesc)
@@ -71,6 +83,15 @@ SIGNATURES = {
     "sempyr_axpby": [_P, _P, c_float, c_float, _P, c_int64, _P],
     "sempyr_adam_step": [ctypes.POINTER(AdamTensor), c_int, c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                          ctypes.c_double, ctypes.c_double, c_int, _P],
+    "sempyr_adam_scalars": [c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_float)],
+    "sempyr_adam_step_dev": [ctypes.POINTER(AdamTensor), c_int, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                             ctypes.c_double, c_int, _P],
+    "sempyr_store_words": [ctypes.POINTER(ctypes.c_uint32), c_int, _P, _P],
+    "sempyr_build_masks": [ctypes.POINTER(MaskTarget), c_int, _P, _P],
+    "sempyr_concat": [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int, _P, _P],
+    "sempyr_fill_const": [_P, c_float, c_int64, _P],
+    "sempyr_lincomb": [ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, c_float, c_float, _P, _P],
+    "sempyr_accumulate_many": [ctypes.POINTER(AccumItem), c_int, _P],
     "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],
     "sempyr_normalize": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "sempyr_pool2_down": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
@@ -85,6 +106,9 @@ SIGNATURES = {
     "sempyr_gp_fwd": [_P, c_int, c_int, _P, _P, _P, _P],
     "sempyr_gp_bwd": [_P, _P, _P, c_int, c_int, _P, _P],
     "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P],
+    "sempyr_replay_create": [_P, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32)],
+    "sempyr_replay_launch": [_P, _P],
+    "sempyr_replay_destroy": [_P],
     "sempyr_profile_begin": [c_int],
     "sempyr_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
 }

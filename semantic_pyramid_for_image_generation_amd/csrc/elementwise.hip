@@ -330,6 +330,117 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __rest
     gx[i] = g;
 }
 
+// ---- small device-resident parameter blocks (inputs of captured HIP graphs) -------------------------------------------
+// up to STORE_MAX 32-bit words travel in the kernel arguments and are written to device memory: a stream-ordered host ->
+// device hand-over of a few scalars without a pinned staging buffer (nothing to keep alive, nothing to reuse too early)
+constexpr int STORE_MAX = SEMPYR_STORE_MAX_WORDS;
+struct StoreArgs { uint32_t w[STORE_MAX]; int n; };
+__global__ __launch_bounds__(64) void store_words_kernel(const StoreArgs a, uint32_t* __restrict__ dst)
+{
+    const int i = threadIdx.x;
+    if (i < a.n) dst[i] = a.w[i];
+}
+
+// the six feature masks of train_model.py:172-209 in one launch: mask t is `base` everywhere except the window
+// rows [x0,x1) x cols [y0,y1) which hold `win`; the six-word spec of every mask is read from device memory
+struct MaskArgs {
+    float* ptr[SEMPYR_MASKS_MAX];
+    long long first[SEMPYR_MASKS_MAX + 1];        // first thread of each mask
+    int H[SEMPYR_MASKS_MAX], W[SEMPYR_MASKS_MAX], vec[SEMPYR_MASKS_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void build_masks_kernel(const MaskArgs a, const int32_t* __restrict__ spec)
+{
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= a.first[a.n]) return;
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < SEMPYR_MASKS_MAX; ++k) if (k < a.n && tid >= a.first[k]) t = k;
+    const int32_t* sp = spec + 6 * t;
+    const float base = __int_as_float(sp[0]), win = __int_as_float(sp[1]);
+    const int x0 = sp[2], x1 = sp[3], y0 = sp[4], y1 = sp[5];
+    const int H = a.H[t], W = a.W[t];
+    const long long local = tid - a.first[t];
+    if (a.vec[t]) {
+        const long long e = local * 4;
+        const int wq = (int)(e % W);
+        const int h = (int)((e / W) % H);
+        const bool rowin = h >= x0 && h < x1;
+        float4 v;
+        v.x = (rowin && wq + 0 >= y0 && wq + 0 < y1) ? win : base;
+        v.y = (rowin && wq + 1 >= y0 && wq + 1 < y1) ? win : base;
+        v.z = (rowin && wq + 2 >= y0 && wq + 2 < y1) ? win : base;
+        v.w = (rowin && wq + 3 >= y0 && wq + 3 < y1) ? win : base;
+        *reinterpret_cast<float4*>(a.ptr[t] + e) = v;
+    } else {
+        const int wq = (int)(local % W);
+        const int h = (int)((local / W) % H);
+        a.ptr[t][local] = (h >= x0 && h < x1 && wq >= y0 && wq < y1) ? win : base;
+    }
+}
+
+// ---- glue that replaces torch's own tiny kernels inside the loop body -------------------------------------------------
+struct ConcatArgs { const float* src[SEMPYR_CONCAT_MAX]; long long first[SEMPYR_CONCAT_MAX + 1]; int n; };
+// dst = [src0 | src1 | ...] (float4 granules; every part's length and start are multiples of 4 floats)
+__global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a, float* __restrict__ dst)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // float4 index in dst
+    if (i >= a.first[a.n]) return;
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < SEMPYR_CONCAT_MAX; ++k) if (k < a.n && i >= a.first[k]) t = k;
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(a.src[t])[i - a.first[t]];
+}
+__global__ __launch_bounds__(256) void concat_scalar_kernel(const ConcatArgs a, float* __restrict__ dst)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.first[a.n]) return;
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < SEMPYR_CONCAT_MAX; ++k) if (k < a.n && i >= a.first[k]) t = k;
+    dst[i] = a.src[t][i - a.first[t]];
+}
+
+__global__ __launch_bounds__(256) void fill_const_kernel(float* __restrict__ dst, float v, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
+// *out = ((w0*x0 + w1*x1 + ...) * s1) * s2 on device scalars, every product and sum rounded separately and summed left to
+// right (what the chain of torch scalar ops it replaces computes)
+struct LincombArgs { const float* x[SEMPYR_LINCOMB_MAX]; float w[SEMPYR_LINCOMB_MAX]; int n; float s1, s2; };
+__global__ void lincomb_kernel(const LincombArgs a, float* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float acc = __fmul_rn(a.w[0], *a.x[0]);
+    for (int i = 1; i < a.n; ++i) acc = __fadd_rn(acc, __fmul_rn(a.w[i], *a.x[i]));
+    acc = __fmul_rn(acc, a.s1);
+    acc = __fmul_rn(acc, a.s2);
+    *out = acc;
+}
+
+// dst_i (+)= src_i for a table of small tensors (parameter-gradient accumulation of a whole backward pass in one launch);
+// a workgroup owns one 1024-element chunk of one pair
+struct AccumArgs { float* dst[SEMPYR_ACCUM_MAX]; const float* src[SEMPYR_ACCUM_MAX][SEMPYR_ACCUM_SRCS]; int numel[SEMPYR_ACCUM_MAX];
+                   int first_chunk[SEMPYR_ACCUM_MAX + 1]; unsigned long long assign_mask; int n; };
+__global__ __launch_bounds__(256) void accumulate_many_kernel(const AccumArgs a)
+{
+    const int chunk = blockIdx.x;
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.first_chunk[mid] <= chunk) lo = mid; else hi = mid - 1; }
+    const int t = lo;
+    const bool assign = (a.assign_mask >> t) & 1ull;
+    float* __restrict__ d = a.dst[t];
+    const int base = (chunk - a.first_chunk[t]) * 1024;
+    for (int i = base + threadIdx.x; i < a.numel[t] && i < base + 1024; i += 256) {
+        float v = assign ? a.src[t][0][i] : d[i] + a.src[t][0][i];          // the sources are added in table order
+#pragma unroll
+        for (int k = 1; k < SEMPYR_ACCUM_SRCS; ++k) if (a.src[t][k]) v += a.src[t][k][i];
+        d[i] = v;
+    }
+}
+
 } // namespace
 
 #define LAUNCH_1D(kernel, nthreads, st, ...) do { \
@@ -468,5 +579,100 @@ extern "C" int sempyr_maxpool3s2_bwd(const float* gy, const int32_t* idx, float*
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)rows * H * W;
     LAUNCH_1D(maxpool3s2_bwd_kernel, total, (hipStream_t)stream, gy, idx, gx, total, H, W, Ho, Wo);
+    return 0;
+}
+
+extern "C" int sempyr_store_words(const uint32_t* words_host, int n, uint32_t* dst_dev, void* stream)
+{
+    if (!words_host || !dst_dev || n < 1 || n > STORE_MAX) SEMPYR_FAIL("store_words: 1..%d words expected (got %d)", STORE_MAX, n);
+    StoreArgs a;
+    for (int i = 0; i < n; ++i) a.w[i] = words_host[i];
+    a.n = n;
+    hipLaunchKernelGGL(store_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, dst_dev);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_build_masks(const sempyr_mask_target* targets, int n, const int32_t* spec_dev, void* stream)
+{
+    if (!targets || !spec_dev || n < 1 || n > SEMPYR_MASKS_MAX) SEMPYR_FAIL("build_masks: 1..%d masks expected (got %d)", SEMPYR_MASKS_MAX, n);
+    MaskArgs a;
+    long long threads = 0;
+    for (int i = 0; i < n; ++i) {
+        const sempyr_mask_target& t = targets[i];
+        if (!t.mask || t.rows < 1 || t.H < 1 || t.W < 1) SEMPYR_FAIL("build_masks: mask %d has a null pointer or an empty shape", i);
+        const long long numel = (long long)t.rows * t.H * t.W;
+        if (numel >= (1ll << 31)) SEMPYR_FAIL("build_masks: mask %d has %lld elements", i, numel);
+        a.ptr[i] = t.mask; a.H[i] = t.H; a.W[i] = t.W;
+        a.vec[i] = (t.W % 4 == 0) && aligned16(t.mask);
+        a.first[i] = threads;
+        threads += a.vec[i] ? numel / 4 : numel;
+    }
+    a.first[n] = threads; a.n = n;
+    for (int i = n; i < SEMPYR_MASKS_MAX; ++i) { a.ptr[i] = nullptr; a.H[i] = a.W[i] = 1; a.vec[i] = 0; a.first[i + 1] = threads; }
+    LAUNCH_1D(build_masks_kernel, threads, (hipStream_t)stream, a, spec_dev);
+    return 0;
+}
+
+extern "C" int sempyr_concat(const float* const* srcs_host, const int64_t* numels_host, int n, float* dst, void* stream)
+{
+    if (!srcs_host || !numels_host || !dst || n < 1 || n > SEMPYR_CONCAT_MAX) SEMPYR_FAIL("concat: 1..%d sources expected (got %d)", SEMPYR_CONCAT_MAX, n);
+    bool vec = aligned16(dst);
+    for (int i = 0; i < n; ++i) {
+        if (!srcs_host[i] || numels_host[i] < 1) SEMPYR_FAIL("concat: source %d is empty", i);
+        vec = vec && aligned16(srcs_host[i]) && (numels_host[i] % 4 == 0);
+    }
+    ConcatArgs a;
+    long long off = 0;
+    for (int i = 0; i < n; ++i) { a.src[i] = srcs_host[i]; a.first[i] = off; off += vec ? numels_host[i] / 4 : numels_host[i]; }
+    for (int i = n; i < SEMPYR_CONCAT_MAX; ++i) { a.src[i] = nullptr; a.first[i + 1] = off; }
+    a.first[n] = off; a.n = n;
+    if (vec) LAUNCH_1D(concat_kernel, off, (hipStream_t)stream, a, dst);
+    else LAUNCH_1D(concat_scalar_kernel, off, (hipStream_t)stream, a, dst);
+    return 0;
+}
+
+extern "C" int sempyr_fill_const(float* dst, float value, int64_t n, void* stream)
+{
+    if (!dst || n < 1) SEMPYR_FAIL("fill_const: bad arguments");
+    LAUNCH_1D(fill_const_kernel, n, (hipStream_t)stream, dst, value, (long long)n);
+    return 0;
+}
+
+extern "C" int sempyr_lincomb(const float* const* xs_host, const float* ws_host, int n, float s1, float s2, float* out, void* stream)
+{
+    if (!xs_host || !ws_host || !out || n < 1 || n > SEMPYR_LINCOMB_MAX) SEMPYR_FAIL("lincomb: 1..%d terms expected (got %d)", SEMPYR_LINCOMB_MAX, n);
+    LincombArgs a;
+    for (int i = 0; i < n; ++i) { if (!xs_host[i]) SEMPYR_FAIL("lincomb: term %d is null", i); a.x[i] = xs_host[i]; a.w[i] = ws_host[i]; }
+    for (int i = n; i < SEMPYR_LINCOMB_MAX; ++i) { a.x[i] = nullptr; a.w[i] = 0.f; }
+    a.n = n; a.s1 = s1; a.s2 = s2;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_accumulate_many(const sempyr_accum_item* items_host, int n, void* stream)
+{
+    if (!items_host || n < 1) SEMPYR_FAIL("accumulate_many: empty table");
+    for (int first = 0; first < n; first += SEMPYR_ACCUM_MAX) {
+        const int m = n - first < SEMPYR_ACCUM_MAX ? n - first : SEMPYR_ACCUM_MAX;
+        AccumArgs a;
+        a.assign_mask = 0ull;
+        long long chunks = 0;
+        for (int i = 0; i < m; ++i) {
+            const sempyr_accum_item& it = items_host[first + i];
+            if (!it.dst || !it.src[0] || it.numel < 1 || it.numel >= (1ll << 31)) SEMPYR_FAIL("accumulate_many: bad item %d", first + i);
+            for (int j = 0; j < first + i; ++j)
+                if (items_host[j].dst == it.dst && j >= first) SEMPYR_FAIL("accumulate_many: destination of item %d repeats in one launch", first + i);
+            a.dst[i] = it.dst; a.numel[i] = (int)it.numel; a.first_chunk[i] = (int)chunks;
+            for (int k = 0; k < SEMPYR_ACCUM_SRCS; ++k) a.src[i][k] = it.src[k];
+            if (it.assign) a.assign_mask |= 1ull << i;
+            chunks += (it.numel + 1023) / 1024;
+        }
+        if (chunks >= (1ll << 31)) SEMPYR_FAIL("accumulate_many: too many elements");
+        a.first_chunk[m] = (int)chunks; a.n = m;
+        hipLaunchKernelGGL(accumulate_many_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
+        SEMPYR_CHECK_LAUNCH();
+    }
     return 0;
 }

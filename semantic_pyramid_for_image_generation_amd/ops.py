@@ -76,6 +76,26 @@ def _p(t):
 
 _REDUCE_SCRATCH = L.sempyr_reduce_scratch_floats()
 
+# HIP-graph capture (loop.py).  CAPTURE_EPOCH is 0 in eager execution and a unique positive id while a loop body is being
+# captured.  Events recorded during a capture only exist inside that capture: cached objects that carry an event (packed
+# weights) remember the epoch it was recorded in, and a reader only waits on the event when it runs in the same epoch --
+# anything older is complete by construction (the device is synchronised before a capture begins, and graph launches are
+# ordered on the launching stream).
+CAPTURE_EPOCH = 0
+_EPOCH_COUNTER = [0]
+
+
+class capture_epoch:
+    def __enter__(self):
+        global CAPTURE_EPOCH
+        _EPOCH_COUNTER[0] += 1
+        CAPTURE_EPOCH = _EPOCH_COUNTER[0]
+        return self
+
+    def __exit__(self, *exc):
+        global CAPTURE_EPOCH
+        CAPTURE_EPOCH = 0
+
 # When set, parameter (weight / bias / affine) gradients are skipped in backward passes. Used by
 # gradient_penalty (only d pred / d x is wanted, train_model.py:73) — custom Functions cannot see
 # autograd.grad's `inputs=` pruning, so the caller states it.  A plain module global: the autograd
@@ -120,16 +140,81 @@ def join_side_streams():
 
 
 class async_param_grads:
+    """`with async_param_grads(): loss.backward()` -- inside the block the backward pass hands parameter gradients to this
+    module instead of autograd's AccumulateGrad nodes: weight / bias gradients are computed on the side stream straight into
+    `param.grad` (see above), and the small affine gradients of the norm layers are collected and written into `param.grad`
+    by ONE launch when the block ends (autograd would issue an add kernel per tensor and pass)."""
+
     def __enter__(self):
-        global _ASYNC_ON
-        self._prev = _ASYNC_ON
+        global _ASYNC_ON, _STASH_ON
+        self._prev = (_ASYNC_ON, _STASH_ON)
         _ASYNC_ON = _ASYNC_ENV
+        _STASH_ON = True
         return self
 
     def __exit__(self, *exc):
-        global _ASYNC_ON
-        _ASYNC_ON = self._prev
+        global _ASYNC_ON, _STASH_ON
+        _ASYNC_ON, _STASH_ON = self._prev
         join_side_streams()
+        if not _STASH_ON:
+            flush_param_grads()
+
+
+_STASH_ON = False
+_PENDING = []            # (param, gradient tensor) in the order the backward pass produced them
+
+
+def _stash(param, g):
+    """True when the gradient was taken over (the caller then returns None to autograd for that input)."""
+    if not (_STASH_ON and g is not None and not torch.is_grad_enabled() and _is_leaf_param(param)):
+        return False
+    _PENDING.append((param, g, _current_stream_obj(g.device)))      # remember the stream the gradient is produced on
+    return True
+
+
+def flush_param_grads():
+    """param.grad (+)= g for every collected pair, in collection order, with one launch per 64 pairs on the current stream
+    (every producer stream has been joined by the backward pass / join_side_streams by now)."""
+    if not _PENDING:
+        return
+    pend = list(_PENDING)
+    _PENDING.clear()
+    dev = pend[0][1].device
+    cur = _current_stream_obj(dev)
+    for producer in {id(st): st for _, _, st in pend}.values():
+        if producer != cur:             # no AccumulateGrad node runs for these gradients, so the engine joins nothing: do it here
+            cur.wait_stream(producer)
+    groups = {}                         # parameter -> its gradient contributions, in production order
+    for p, g, producer in pend:
+        g = _req(g, "parameter gradient")
+        if g.numel() != p.numel():
+            raise _lib.SempyrError("flush_param_grads: gradient / parameter size mismatch")
+        if producer != cur:
+            g.record_stream(cur)
+        groups.setdefault(id(p), (p, []))[1].append(g)
+    while groups:
+        batch = list(groups.values())[:32]
+        arr = (_lib.AccumItem * len(batch))()
+        for i, (p, gs) in enumerate(batch):
+            take, rest = gs[:4], gs[4:]
+            dst = _grad_in_place(p)
+            it = arr[i]
+            if dst is None:
+                if p.grad is not None:
+                    raise _lib.SempyrError("flush_param_grads: .grad of a parameter is not a dense fp32 tensor of its shape")
+                dst = torch.empty_like(p)
+                p.grad = dst
+                it.assign = 1
+            else:
+                it.assign = 0
+            it.dst = dst.data_ptr(); it.numel = p.numel()
+            for k in range(4):
+                it.src[k] = take[k].data_ptr() if k < len(take) else None
+            if rest:
+                groups[id(p)] = (p, rest)        # more than four contributions: the rest goes into a later launch
+            else:
+                del groups[id(p)]
+        check(L.sempyr_accumulate_many(arr, len(batch), _raw_stream(dev.index)), "sempyr_accumulate_many")
 
 
 TWO_STREAM_CRITIC = os.environ.get("SEMPYR_TWO_STREAM", "1") != "0"
@@ -172,6 +257,15 @@ def consumer_streams(device):
 
 def _is_leaf_param(t):
     return t is not None and t.is_leaf and t.requires_grad
+
+
+def _weak(t):
+    """a callable returning `t` while it is alive (Function contexts keep parameters they only need for .grad this way)"""
+    import weakref
+    try:
+        return weakref.ref(t)
+    except TypeError:       # pragma: no cover
+        return lambda: t
 
 
 def _accumulate_grad(param, g, main):
@@ -326,7 +420,7 @@ def _packed_weights(plan, w, mode):
         if cache is not None:
             hit = cache.get(wkey)
             if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
-                if hit[4] != _stream():                # packed on another stream: order this stream after the pack kernel
+                if hit[4] != _stream() and hit[7] == CAPTURE_EPOCH:   # packed on another stream: order this stream after the pack kernel
                     cur = torch.cuda.current_stream(w.device)
                     cur.wait_event(hit[3])
                     hit[1].record_stream(cur)
@@ -338,7 +432,7 @@ def _packed_weights(plan, w, mode):
         cur = torch.cuda.current_stream(w.device)
         ev = torch.cuda.Event()
         ev.record(cur)
-        cache[wkey] = (w._version, wp, w.data_ptr(), ev, cur.cuda_stream, plan, mode)
+        cache[wkey] = (w._version, wp, w.data_ptr(), ev, cur.cuda_stream, plan, mode, CAPTURE_EPOCH)
     return wp
 
 
@@ -387,7 +481,7 @@ def repack_cached(params, table_cache=None):
     ev = torch.cuda.Event()
     ev.record(cur)
     for w, wkey, hit in entries:
-        w._sempyr_pack[wkey] = (w._version, hit[1], hit[2], ev, raw, hit[5], hit[6])
+        w._sempyr_pack[wkey] = (w._version, hit[1], hit[2], ev, raw, hit[5], hit[6], CAPTURE_EPOCH)
 
 
 def _workspace(nbytes, device):
@@ -653,6 +747,7 @@ class _NormAct(Function):
             torch.autograd.graph.increment_version(rv)
         ctx.save_for_backward(x, y if act_kind != ACT_NONE else None, gamma, rowbuf)
         ctx.cfg = (kind, act_kind, slope)
+        ctx.beta_ref = _weak(beta)
         return y
 
     @staticmethod
@@ -662,6 +757,11 @@ class _NormAct(Function):
         gx, gg, gb = _apply(_NormActBwd, gy.contiguous(), x, y, gamma, rowbuf, kind, act_kind, slope)
         if _INPUT_GRADS_ONLY:
             gg = gb = None
+        else:
+            if _stash(gamma, gg):
+                gg = None
+            if _stash(ctx.beta_ref(), gb):
+                gb = None
         return gx, gg, gb, None, None, None, None, None
 
 
@@ -693,6 +793,7 @@ class _NormAddNormAct(Function):
               "sempyr_affine2_act")
         ctx.save_for_backward(a, b, y if act_kind != ACT_NONE else None, gamma_a, gamma_b, ra, rb)
         ctx.cfg = (kind, act_kind, slope, b_half)
+        ctx.beta_refs = (_weak(beta_a), _weak(beta_b))
         return y
 
     @staticmethod
@@ -708,6 +809,16 @@ class _NormAddNormAct(Function):
         gb, ggb, gbb = _apply(_NormActBwd, g_b, b, None, gamma_b, rb, kind, ACT_NONE, 0.0)
         if _INPUT_GRADS_ONLY:
             gga = gba = ggb = gbb = None
+        else:
+            beta_a, beta_b = ctx.beta_refs[0](), ctx.beta_refs[1]()
+            if _stash(gamma_a, gga):
+                gga = None
+            if _stash(beta_a, gba):
+                gba = None
+            if _stash(gamma_b, ggb):
+                ggb = None
+            if _stash(beta_b, gbb):
+                gbb = None
         return ga, gga, gba, None, gb, ggb, gbb, None, None, None, None, None, None, None
 
 
@@ -757,6 +868,8 @@ class _NormActBwd(Function):
                                     rowbuf.data_ptr(), rowbuf.data_ptr() + 4 * rows, N, C, HW, act_kind, slope,
                                     g_gy.data_ptr(), g_x.data_ptr(), _p(g_gamma), scratch.data_ptr(), _stream()),
               "sempyr_norm_bwd_bwd")
+        if _stash(gamma, g_gamma):
+            g_gamma = None
         return g_gy, g_x, None, g_gamma, None, None, None, None
 
 
@@ -1131,6 +1244,39 @@ def global_avg_pool(x):
 
 
 # ------------------------------------------------------------------------------------------------
+# per-iteration scalars in device memory (inputs of captured graphs) and the feature masks
+# ------------------------------------------------------------------------------------------------
+def store_words(dst, words):
+    """dst[0:len(words)] = words (Python ints, taken modulo 2**32), stream-ordered; dst is an int32 / float32 device tensor.
+    The words travel in the kernel arguments (no pinned staging buffer whose reuse would need an event)."""
+    n = len(words)
+    if n > _lib.STORE_MAX_WORDS or dst.numel() < n or dst.element_size() != 4 or not dst.is_cuda:
+        raise _lib.SempyrError("store_words: at most %d words into a 4-byte device tensor" % _lib.STORE_MAX_WORDS)
+    arr = (ctypes.c_uint32 * n)(*[w & 0xFFFFFFFF for w in words])
+    check(L.sempyr_store_words(arr, n, dst.data_ptr(), _raw_stream(dst.device.index)), "sempyr_store_words")
+
+
+def float_bits(v):
+    import struct
+    return struct.unpack('<I', struct.pack('<f', v))[0]
+
+
+def build_masks(masks, spec_dev):
+    """Fill the fp32 (N, C, H, W) tensors `masks` from their six-word specs {bits(base), bits(win), x0, x1, y0, y1} held in
+    the int32 device tensor `spec_dev` (train_model.py:172-209), one launch for all of them."""
+    n = len(masks)
+    arr = (_lib.MaskTarget * n)()
+    for i, m in enumerate(masks):
+        _req(m, "mask")
+        if m.dim() != 4 or not m.is_contiguous():
+            raise _lib.SempyrError("build_masks: contiguous (N, C, H, W) tensors expected")
+        arr[i].mask = m.data_ptr(); arr[i].rows = m.shape[0] * m.shape[1]; arr[i].H = m.shape[2]; arr[i].W = m.shape[3]
+    if spec_dev.dtype != torch.int32 or spec_dev.numel() < 6 * n:
+        raise _lib.SempyrError("build_masks: the spec is an int32 tensor of 6 words per mask")
+    check(L.sempyr_build_masks(arr, n, spec_dev.data_ptr(), _raw_stream(masks[0].device.index)), "sempyr_build_masks")
+
+
+# ------------------------------------------------------------------------------------------------
 # loss-path reductions
 # ------------------------------------------------------------------------------------------------
 class _Mean(Function):
@@ -1234,6 +1380,145 @@ class _GPLoss(Function):
 def gp_loss(grad):
     """one_mean_gp(grad) (train_model.py:63-66)."""
     return _apply(_GPLoss, grad)
+
+
+class _ConcatRows(Function):
+    """cat(tensors, dim=0) in one launch; the backward hands out views of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ts = [_req(t, "concat input") for t in tensors]
+        tail = tuple(ts[0].shape[1:])
+        if len(ts) > _lib.CONCAT_MAX or any(tuple(t.shape[1:]) != tail for t in ts):
+            raise _lib.SempyrError("concat_rows: up to %d tensors of equal trailing shape" % _lib.CONCAT_MAX)
+        rows = [t.shape[0] for t in ts]
+        out = torch.empty((sum(rows),) + tail, dtype=torch.float32, device=ts[0].device)
+        srcs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        ns = (ctypes.c_int64 * len(ts))(*[t.numel() for t in ts])
+        check(L.sempyr_concat(srcs, ns, len(ts), out.data_ptr(), _stream()), "sempyr_concat")
+        ctx.rows = rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for i, r in enumerate(ctx.rows):
+            outs.append(g[off:off + r] if ctx.needs_input_grad[i] else None)
+            off += r
+        return tuple(outs)
+
+
+def concat_rows(tensors):
+    """torch.cat(tensors, dim=0) — the real and the fake batch as one critic batch (train_model.py:132-133)."""
+    return _apply(_ConcatRows, *tensors)
+
+
+def gather_scalars(scalars, out_row):
+    """out_row[i] = scalars[i] for up to 8 one-element device tensors, one launch."""
+    n = len(scalars)
+    if n > _lib.CONCAT_MAX or out_row.numel() < n or not out_row.is_contiguous():
+        raise _lib.SempyrError("gather_scalars: up to %d scalars into a contiguous row" % _lib.CONCAT_MAX)
+    srcs = (ctypes.c_void_p * n)(*[_req(v, "scalar").data_ptr() for v in scalars])
+    ns = (ctypes.c_int64 * n)(*([1] * n))
+    check(L.sempyr_concat(srcs, ns, n, out_row.data_ptr(), _stream()), "sempyr_concat")
+
+
+def full_like(t, value):
+    """torch.full_like(t, value) (grad_outputs=torch.ones_like(pred), train_model.py:73)."""
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    check(L.sempyr_fill_const(out.data_ptr(), float(value), out.numel(), _stream()), "sempyr_fill_const")
+    return out
+
+
+def _lincomb_raw(xs, ws, s1, s2):
+    n = len(xs)
+    out = torch.empty((), dtype=torch.float32, device=xs[0].device)
+    px = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    pw = (ctypes.c_float * n)(*ws)
+    check(L.sempyr_lincomb(px, pw, n, s1, s2, out.data_ptr(), _stream()), "sempyr_lincomb")
+    return out
+
+
+class _Lincomb(Function):
+    """((w0*x0 + w1*x1 + ...) * s1) * s2 on 0-d tensors."""
+
+    @staticmethod
+    def forward(ctx, ws, s1, s2, *xs):
+        xs = [_req(x, "loss term") for x in xs]
+        if any(x.numel() != 1 for x in xs) or len(xs) != len(ws) or len(xs) > _lib.LINCOMB_MAX:
+            raise _lib.SempyrError("lincomb: up to %d one-element tensors, one weight each" % _lib.LINCOMB_MAX)
+        ctx.cfg = (tuple(float(w) for w in ws), float(s1), float(s2))
+        return _lincomb_raw(xs, ctx.cfg[0], ctx.cfg[1], ctx.cfg[2])
+
+    @staticmethod
+    def backward(ctx, g):
+        ws, s1, s2 = ctx.cfg
+        if torch.is_grad_enabled() and g.requires_grad:
+            raise NotImplementedError("double backward through the loss arithmetic is not part of the hot path")
+        g = _req(g, "grad")
+        outs = []
+        cache = {}
+        for i, w in enumerate(ws):
+            if not ctx.needs_input_grad[3 + i]:
+                outs.append(None)
+                continue
+            if w == 1.0 and s1 == 1.0 and s2 == 1.0:
+                outs.append(g)
+                continue
+            if w not in cache:
+                cache[w] = _lincomb_raw([g], [s2], s1, w)          # ((g*s2)*s1)*w : the order of the chain of torch ops
+            outs.append(cache[w])
+        return (None, None, None) + tuple(outs)
+
+
+def lincomb(xs, ws=None, s1=1.0, s2=1.0):
+    """The scalar loss arithmetic of the step functions (train_model.py:101-103,112,138,222) in one launch."""
+    ws = [1.0] * len(xs) if ws is None else ws
+    return _apply(_Lincomb, tuple(ws), s1, s2, *xs)
+
+
+class _MeanParts(Function):
+    """(scale_i * mean(x[start_i : start_i + rows_i]))_i for consecutive row blocks of x."""
+
+    @staticmethod
+    def forward(ctx, x, rows, scales):
+        x = _req(x, "input")
+        if sum(rows) != x.shape[0] or len(rows) != len(scales):
+            raise _lib.SempyrError("mean_parts: the row blocks must cover the tensor")
+        per = x.numel() // x.shape[0]
+        outs, off = [], 0
+        for r, sc in zip(rows, scales):
+            out = torch.empty((), dtype=torch.float32, device=x.device)
+            scratch = torch.empty(_REDUCE_SCRATCH, dtype=torch.float32, device=x.device)
+            check(L.sempyr_mean(x.data_ptr() + 4 * off * per, r * per, sc, out.data_ptr(), scratch.data_ptr(), _stream()), "sempyr_mean")
+            outs.append(out)
+            off += r
+        ctx.cfg = (tuple(rows), tuple(scales), tuple(x.shape), per)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        rows, scales, shape, per = ctx.cfg
+        if any(g is not None and torch.is_grad_enabled() and g.requires_grad for g in gs):
+            raise NotImplementedError("double backward through a mean is not part of the hot path")
+        dev = next(g for g in gs if g is not None).device
+        gx = torch.empty(shape, dtype=torch.float32, device=dev)
+        off = 0
+        for r, sc, g in zip(rows, scales, gs):
+            dst = gx.data_ptr() + 4 * off * per
+            if g is None:
+                check(L.sempyr_fill_const(dst, 0.0, r * per, _stream()), "sempyr_fill_const")
+            else:
+                check(L.sempyr_fill_scalar(_req(g, "grad").data_ptr(), sc / (r * per), dst, r * per, _stream()), "sempyr_fill_scalar")
+            off += r
+        return gx, None, None
+
+
+def mean_parts(x, rows, scales):
+    """The WGAN critic losses (-mean(real logits), mean(fake logits)) of train_model.py:39-42 taken from ONE logits tensor
+    of the batched critic pass, without slicing it (a slice's backward is a fill + copy + add in torch)."""
+    return _apply(_MeanParts, x, tuple(rows), tuple(scales))
 
 
 def lerp_rows(real, fake, alpha):

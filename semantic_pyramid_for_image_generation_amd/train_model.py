@@ -47,6 +47,7 @@ def get_wgan_losses_fn():
     def g_loss_fn(f_logit):
         return ops.mean(f_logit, -1.0)
 
+    d_loss_fn._sempyr_wgan = True
     return d_loss_fn, g_loss_fn
 
 
@@ -59,32 +60,77 @@ def sample_line(real, fake, alpha=None):
     return ops.lerp_rows(real, fake, alpha)
 
 
+def _row_scale(x, coef):
+    """out[r, :] = x[r, :] * coef[r]"""
+    rows = x.size(0)
+    c = torch.cat([coef.reshape(-1).float(), torch.zeros(rows, dtype=torch.float32, device=x.device)])
+    out = torch.empty_like(x)
+    ops.check(ops.L.sempyr_affine_act(x.data_ptr(), 0, c.data_ptr(), c.data_ptr() + 4 * rows, 0, out.data_ptr(), rows,
+                                      x.numel() // rows, ops.ACT_NONE, 0.0, ops._stream()), "sempyr_affine_act")
+    return out
+
+
+def _row_dot(a, b):
+    """[rows] vector of <a[r, :], b[r, :]>"""
+    rows = a.size(0)
+    prod = torch.empty_like(a)
+    ops.check(ops.L.sempyr_mul(a.data_ptr(), b.data_ptr(), prod.data_ptr(), a.numel(), ops._stream()), "sempyr_mul")
+    out = torch.empty(rows, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(rows, dtype=torch.float32, device=a.device)
+    ops.check(ops.L.sempyr_channel_sum(prod.data_ptr(), 1, rows, a.numel() // rows, 1.0, out.data_ptr(), 0, scratch.data_ptr(),
+                                       ops._stream()), "sempyr_channel_sum")
+    return out
+
+
 class _RowNorm(torch.autograd.Function):
+    """norms[r] = ||x[r, :]||_2"""
+
     @staticmethod
     def forward(ctx, x):
         rows = x.size(0)
-        x = x.contiguous()
+        x = ops._req(x, "norm input")
         norms = torch.empty(rows, dtype=torch.float32, device=x.device)
         gp = torch.empty((), dtype=torch.float32, device=x.device)
-        ops.check(ops.L.sempyr_gp_fwd(x.data_ptr(), rows, x.numel() // rows, norms.data_ptr(), gp.data_ptr(), ops._stream()),
+        ops.check(ops.L.sempyr_gp_fwd(x.data_ptr(), rows, x.numel() // rows, norms.data_ptr(), gp.data_ptr(), 0, ops._stream()),
                   "sempyr_gp_fwd")
         ctx.save_for_backward(x, norms)
         return norms
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         x, norms = ctx.saved_tensors
-        rows = x.size(0)
-        coef = torch.cat([g / norms, torch.zeros_like(norms)])
-        out = torch.empty_like(x)
-        ops.check(ops.L.sempyr_affine_act(x.data_ptr(), 0, coef.data_ptr(), coef.data_ptr() + 4 * rows, 0, out.data_ptr(), rows,
-                                          x.numel() // rows, ops.ACT_NONE, 0.0, ops._stream()), "sempyr_affine_act")
-        return out
+        return _RowNormBwd.apply(g.contiguous(), x, norms)
+
+
+class _RowNormBwd(torch.autograd.Function):
+    """gx[r, :] = g[r] * x[r, :] / n[r] (0 where n[r] == 0, as torch's norm backward); differentiable in g and x, which is
+    what a gradient penalty composed by hand from norm() (reference train_model.py:58-66 under create_graph=True) needs."""
+
+    @staticmethod
+    def forward(ctx, g, x, norms):
+        inv = torch.where(norms > 0, 1.0 / norms, torch.zeros_like(norms))
+        ctx.save_for_backward(g, x, inv)
+        return _row_scale(x, g * inv)
+
+    @staticmethod
+    def backward(ctx, u):
+        g, x, inv = ctx.saved_tensors
+        u = u.contiguous()
+        xu = _row_dot(x, u)                                   # <x_r, u_r>
+        g_g = xu * inv if ctx.needs_input_grad[0] else None
+        g_x = None
+        if ctx.needs_input_grad[1]:
+            # d/dx [g x / n] . u = g (u / n - x <x,u> / n^3)
+            a = _row_scale(u, g * inv)
+            b = _row_scale(x, -(g * xu) * inv * inv * inv)
+            g_x = torch.empty_like(x)
+            ops.check(ops.L.sempyr_axpby(a.data_ptr(), b.data_ptr(), 1.0, 1.0, g_x.data_ptr(), x.numel(), ops._stream()),
+                      "sempyr_axpby")
+        return g_g, g_x, None
 
 
 def norm(x):
-    """per-sample L2 norm over all non-batch dims (reference :58-60)."""
+    """per-sample L2 norm over all non-batch dims (reference :58-60); twice differentiable."""
     return _RowNorm.apply(x)
 
 
@@ -100,7 +146,7 @@ def gradient_penalty(f, real, fake, alpha=None):
     x.requires_grad = True
     pred = f(x)
     with ops.input_grads_only():
-        grad = torch.autograd.grad(pred, x, grad_outputs=torch.ones_like(pred), create_graph=True)[0]
+        grad = torch.autograd.grad(pred, x, grad_outputs=ops.full_like(pred, 1.0), create_graph=True)[0]
     return one_mean_gp(grad)
 
 
@@ -195,7 +241,7 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
             main.wait_stream(side)
             generator_loss.record_stream(main)
 
-        total_loss = generator_loss + features_loss
+        total_loss = ops.lincomb([generator_loss, features_loss])
         loses_dictionary = {'g_loss': generator_loss, 'features_loss': features_loss, 'total_loss': total_loss}
 
         if args.use_diversity_loss:
@@ -203,23 +249,33 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
                 z2 = torch.randn(batch_size, 128, 1, 1, device=device)
             fake_images2 = generator(z2, features, masks)
             diversity_loss = criterion_diversity_n(z, z2) / (criterion_diversity_d(fake_images, fake_images2) + epsilon)
-            total_loss = total_loss + diversity_loss
+            total_loss = ops.lincomb([total_loss, diversity_loss])
             loses_dictionary['diversity loss'] = diversity_loss
             loses_dictionary['total loss'] = total_loss
 
         generator.zero_grad()
         with ops.async_param_grads():
-            total_loss.backward()
+            total_loss.backward(_one(device))
     parallel.sync_gradients(generator)
     generator_optimizer.step()
-    if device.type == 'cuda':
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        _GEN_UPDATED[id(generator)] = ev
+    mark_generator_updated(generator, device)
     return loses_dictionary
 
 
 _GEN_UPDATED = {}        # id(generator) -> event recorded behind its last optimizer step
+
+
+def mark_generator_updated(generator, device):
+    """Record, on the current stream, that the generator's parameters have just been updated (the prefetch stream waits for
+    this before the next generator forward).  Inside a graph capture nothing is recorded -- an event of a capture means
+    nothing outside it; whoever replays the capture calls this after the replay (loop.py)."""
+    if device.type == 'cuda':
+        if torch.cuda.is_current_stream_capturing():
+            _GEN_UPDATED.pop(id(generator), None)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            _GEN_UPDATED[id(generator)] = ev
 
 
 class prefetch:
@@ -231,7 +287,7 @@ class prefetch:
     Outside CUDA (or with SEMPYR_PREFETCH=0) the block runs in place."""
 
     def __init__(self, generator, device):
-        self.on = ops.PREFETCH and device.type == 'cuda'
+        self.on = ops.PREFETCH and device.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
         self.generator, self.device = generator, device
         self.done = None
 
@@ -251,6 +307,8 @@ class prefetch:
         if self.on:
             for t in tensors:
                 for item in (t if isinstance(t, (list, tuple)) else [t]):
+                    if item is None:
+                        continue
                     for st in self.consumers:
                         item.record_stream(st)
 
@@ -268,7 +326,7 @@ class prefetch:
 
 def _wait_for_generator_update(generator, device):
     """Order the current stream behind the generator's last optimizer step (it may have been issued on another stream)."""
-    if device.type == 'cuda':
+    if device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
         ev = _GEN_UPDATED.get(id(generator))
         if ev is not None:
             torch.cuda.current_stream(device).wait_event(ev)
@@ -296,12 +354,14 @@ def fake_for_discriminator(generator, batch_size, features, masks, z=None):
 _PINNED = {}
 
 
-def _cpu_randn_to(device, *shape):
+def _cpu_randn_to(device, *shape, out=None):
     """`torch.randn(*shape).to(device)` (same draws from the CPU generator as the reference, train_model.py:125) without
     the host-device synchronisation of a pageable copy: the noise is drawn into one of a small ring of pinned buffers and
-    copied asynchronously; a buffer is reused only after the event recorded behind its last copy has completed."""
+    copied asynchronously; a buffer is reused only after the event recorded behind its last copy has completed.
+    `out`: an existing device tensor that receives the noise."""
     if device.type != 'cuda':
-        return torch.randn(*shape).to(device)
+        z = torch.randn(*shape).to(device)
+        return z if out is None else out.copy_(z)
     ring = _PINNED.setdefault((device.index, shape), {'bufs': [], 'next': 0})
     if len(ring['bufs']) < 8:
         ring['bufs'].append([torch.empty(shape, dtype=torch.float32).pin_memory(), None])
@@ -311,11 +371,31 @@ def _cpu_randn_to(device, *shape):
         ring['next'] = (ring['next'] + 1) % len(ring['bufs'])
         slot[1].synchronize()
     torch.randn(shape, out=slot[0])
-    z = slot[0].to(device, non_blocking=True)
+    z = slot[0].to(device, non_blocking=True) if out is None else out.copy_(slot[0], non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(device))
     slot[1] = ev
     return z
+
+
+_ONE = {}
+
+
+def _one(device):
+    """the constant 1.0 that seeds a backward pass (loss.backward() would launch a fill for it every time)"""
+    t = _ONE.get(device)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _ONE[device] = t
+    return t
+
+
+def _critic_losses_batched(discriminator_loss_fn, logits, n_real, n_fake):
+    """discriminator_loss_fn(logits[:n_real], logits[n_real:]) for the WGAN loss pair of get_wgan_losses_fn, computed from the
+    batched logits without slicing; any other loss function gets the slices."""
+    if getattr(discriminator_loss_fn, '_sempyr_wgan', False):
+        return ops.mean_parts(logits, (n_real, n_fake), (-1.0, 1.0))
+    return discriminator_loss_fn(logits[:n_real], logits[n_real:])
 
 
 def _samplewise(module):
@@ -333,19 +413,22 @@ def train_discriminator(generator, discriminator, discriminator_loss_fn, discrim
     if fake_images is None:                                               # reference: forward with graph, then .detach()
         fake_images = fake_for_discriminator(generator, real_images.shape[0], features, masks, z)   # CPU-generator z (Q7)
 
+    samplewise = _samplewise(discriminator)
+
     def logits_loss():
-        if _samplewise(discriminator):
+        if samplewise:
             # no layer mixes samples (instance / layer norm or none): one pass over both batches gives the same logits as
             # the reference's two passes and fills the small late layers twice as well
-            n = real_images.shape[0]
-            logits = discriminator(torch.cat([real_images, fake_images]))
-            return discriminator_loss_fn(logits[:n], logits[n:])
+            n, m = real_images.shape[0], fake_images.shape[0]
+            logits = discriminator(ops.concat_rows([real_images, fake_images]))
+            return _critic_losses_batched(discriminator_loss_fn, logits, n, m)
         return discriminator_loss_fn(discriminator(real_images), discriminator(fake_images))
 
-    if ops.TWO_STREAM_CRITIC and real_images.is_cuda:
+    if ops.TWO_STREAM_CRITIC and real_images.is_cuda and samplewise:
         # the logit branch and the gradient-penalty branch share nothing but the weights: run them on two streams (the
         # autograd engine replays each branch's backward on the stream of its forward), so their many mid-size kernels
-        # fill each other's idle CUs
+        # fill each other's idle CUs.  Not with a BatchNorm critic: its running statistics are read-modify-written by
+        # every pass, in the reference's order real, fake, x_hat
         main = torch.cuda.current_stream(device)
         side = ops.side_stream(device)
         side.wait_stream(main)
@@ -359,14 +442,16 @@ def train_discriminator(generator, discriminator, discriminator_loss_fn, discrim
         real_images_d_loss, fake_images_d_loss = logits_loss()
         gp = gradient_penalty(discriminator, real_images, fake_images, alpha)
 
-    discriminator_loss = (real_images_d_loss + fake_images_d_loss) + gp * args.gradient_penalty_weight
+    # (real + fake) + gp * weight, and real + fake for the log: one launch each
+    discriminator_loss = ops.lincomb([real_images_d_loss, fake_images_d_loss, gp], [1.0, 1.0, args.gradient_penalty_weight])
+    d_loss = ops.lincomb([real_images_d_loss.detach(), fake_images_d_loss.detach()])
 
     discriminator.zero_grad()
     with ops.async_param_grads():
-        discriminator_loss.backward()
+        discriminator_loss.backward(_one(device))
     parallel.sync_gradients(discriminator)
     discriminator_optimizer.step()
-    return {'d_loss': real_images_d_loss + fake_images_d_loss, 'gp': gp}
+    return {'d_loss': d_loss, 'gp': gp}
 
 
 def sample(generator, z, features, masks):
@@ -398,22 +483,74 @@ def setCroppedMask(random_crop, mask, window_len1=0.45, window_len2=0.45, window
     return mask
 
 
+def crop_window(random_crop, H, W, window_len1=0.45, window_len2=0.45):
+    """(x0, x1, y0, y1): the rows / columns setCroppedMask overwrites, with the clamping of Python slicing."""
+    x_start = math.floor((random_crop[0] / 100) * H)
+    y_start = math.floor((random_crop[1] / 100) * W)
+    x_end = x_start + math.floor(window_len1 * H)
+    y_end = y_start + math.floor(window_len2 * W)
+    return min(x_start, H), min(x_end, H), min(y_start, W), min(y_end, W)
+
+
+def mask_specs(shapes, train_type_is_1, random_layer_idx, random_crop=None):
+    """One (base, win, x0, x1, y0, y1) per mask: the mask is `base` except rows [x0,x1) x cols [y0,y1) = `win`.
+    setMasksPart1 (train type 1: the chosen layer whole, every other layer blocked) or setMasksPart2 (type 2: layers
+    below the chosen one pass with a zeroed window; the chosen layer and the ones above it are blocked -- the reference's
+    loop overwrites the ones it first stores at the chosen index, quirk Q2)."""
+    specs = []
+    for idx, shp in enumerate(shapes):
+        if train_type_is_1:
+            specs.append((1.0, 1.0, 0, 0, 0, 0) if idx == random_layer_idx else (0.0, 0.0, 0, 0, 0, 0))
+        elif idx < random_layer_idx:
+            specs.append((1.0, 0.0) + crop_window(random_crop, shp[2], shp[3]))
+        else:
+            specs.append((0.0, 0.0, 0, 0, 0, 0))
+    return specs
+
+
+def spec_words(specs):
+    words = []
+    for base, win, x0, x1, y0, y1 in specs:
+        words += [ops.float_bits(base), ops.float_bits(win), x0, x1, y0, y1]
+    return words
+
+
+def tag_mask(mask, spec):
+    """Host-side note of what a mask holds, for consumers that can skip work on an all-zero mask without reading it.
+    Only the all-zero property is recorded (it is fixed by train type and layer; window positions change per iteration)."""
+    base, win, x0, x1, y0, y1 = spec
+    mask._sempyr_all_zero = (base == 0.0 and (win == 0.0 or x0 >= x1 or y0 >= y1))
+    return mask
+
+
+def _masks_from_specs(masks, device, specs):
+    device = torch.device(device)
+    if device.type != 'cuda':
+        # host path (CPU tensors only appear in host-logic tests and tooling; the train loop runs on the GPU)
+        for idx, (base, win, x0, x1, y0, y1) in enumerate(specs):
+            m = torch.full(masks[idx].shape, base, dtype=torch.float32, device=device)
+            m[:, :, x0:x1, y0:y1] = win
+            masks[idx] = tag_mask(m, specs[idx])
+        return
+    out = [torch.empty(m.shape, dtype=torch.float32, device=device) for m in masks]
+    spec_dev = torch.empty(6 * len(out), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        ops.store_words(spec_dev, spec_words(specs))
+        ops.build_masks(out, spec_dev)
+    for idx, m in enumerate(out):
+        masks[idx] = tag_mask(m, specs[idx])
+
+
 def setMasksPart1(masks, device, random_layer_idx):
-    """train type 1: pass the chosen layer whole, block every other layer."""
-    for idx, mask in enumerate(masks):
-        masks[idx] = torch.ones(mask.shape, device=device) if idx == random_layer_idx else mask * 0
+    """train type 1: pass the chosen layer whole, block every other layer (reference :184-194); one launch for all masks."""
+    _masks_from_specs(masks, device, mask_specs([m.shape for m in masks], True, random_layer_idx))
 
 
 def setMasksPart2(masks, device, random_layer_idx):
-    """train type 2: layers below the chosen one pass with a zeroed random window; the chosen layer and the ones above
-    it are blocked (the reference's loop overwrites the ones it first stores at the chosen index — quirk Q2)."""
+    """train type 2 (reference :197-209): layers below the chosen one pass with a zeroed random window; the chosen layer
+    and the ones above it are blocked (quirk Q2).  Draws the crop with two random.randint(20, 40) calls."""
     random_crop = (random.randint(20, 40), random.randint(20, 40))
-    masks[random_layer_idx] = torch.ones(masks[random_layer_idx].shape, device=device)
-    for idx, mask in enumerate(masks):
-        if idx < random_layer_idx:
-            masks[idx] = setCroppedMask(random_crop, torch.ones(mask.shape, device=device))
-        else:
-            masks[idx] = mask * 0
+    _masks_from_specs(masks, device, mask_specs([m.shape for m in masks], False, random_layer_idx, random_crop))
 
 
 def getLossByTrainType(features, masks, train_type, features_to_train, outputs_images_features, criterion_features):
@@ -427,11 +564,14 @@ def getLossByTrainType(features, masks, train_type, features_to_train, outputs_i
         return criterion_features(ops.mul(features[i], masks[i]), ops.mul(outputs_images_features[i], masks[i]))
 
     if train_type == 1:
-        loss_features = criterion_features(features[features_to_train], outputs_images_features[features_to_train])
+        terms = [criterion_features(features[features_to_train], outputs_images_features[features_to_train])]
     else:
-        loss_features = term(1)
-        for i in range(2, features_to_train + 1):
-            loss_features = loss_features + term(i)
+        terms = [term(i) for i in range(1, features_to_train + 1)]
+    if all(t.is_cuda for t in terms):
+        return ops.lincomb(terms, None, 1 / features_to_train, 200.0)        # (sum * (1/L)) * 200 in one launch
+    loss_features = terms[0]
+    for t in terms[1:]:
+        loss_features = loss_features + t
     return loss_features * (1 / features_to_train) * 200
 
 
@@ -477,12 +617,14 @@ def _main():
     parallel.broadcast_module(generator)
     parallel.broadcast_module(discriminator)
 
-    criterion_discriminator, criterion_generator = get_wgan_losses_fn()
-    criterion_features = L1Loss()
-    criterion_diversity_n = L1Loss()
-    criterion_diversity_d = L1Loss()
-    generator_optimizer = optim.Adam(generator.parameters(), lr=args.lr, betas=(0.5, 0.999))
-    discriminator_optimizer = optim.Adam(discriminator.parameters(), lr=args.lr, betas=(0.5, 0.999))
+    generator_optimizer = optim.Adam(generator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True)
+    discriminator_optimizer = optim.Adam(discriminator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True)
+    from .loop import TrainLoop
+    # the loop body (reference :300-349) lives in TrainLoop: same draws in the same order, the same step functions above,
+    # replayed from captured graphs after the first occurrence of each variant
+    loop = TrainLoop(generator, discriminator, classifier, generator_optimizer, discriminator_optimizer, args.batch_size, device,
+                     discriminator_steps=args.discriminator_steps, train1_prob=args.train1_prob, fixed_layer=args.fixed_layer,
+                     normalizer_clf=normalizer_clf, normalizer_discriminator=normalizer_discriminator)
 
     starting_time = time.time()
     iterations = 0
@@ -499,27 +641,22 @@ def _main():
     z2 = torch.randn(args.batch_size, 128, 1, 1).to(device)
     fixed_features = fixed_masks = fixed_features_diversity = None
     first_iter = True
-    pending = []                 # (tag, step, device scalar) logged without a per-iteration host sync
     print("Starting Training Loop...")
     for epoch in range(args.epochs):
+        if hasattr(train_loader, 'sampler') and hasattr(train_loader.sampler, 'set_epoch'):
+            train_loader.sampler.set_epoch(epoch)          # data-parallel runs: a new permutation every epoch, as the reference's shuffle
         for data in train_loader:
-            train_type = random.choices([1, 2], [args.train1_prob, 1 - args.train1_prob])
             iterations += 1
             if iterations % 30 == 1:
                 print('epoch:', epoch, ', iter', iterations, 'start, time =', time.time() - starting_time, 'seconds')
                 starting_time = time.time()
             images, _ = data
-            # everything up to the critic's own forward is independent of the previous critic step: it runs on the
-            # prefetch stream and overlaps that step's backward (see `prefetch`)
-            pf = prefetch(generator, device)
-            pf.__enter__()
             images = images.to(device, non_blocking=True)
-            images_discriminator = normalizer_discriminator(images)
-            images_clf = normalizer_clf(images)
-            with torch.no_grad():
-                _, features = classifier(images_clf)
+            out = loop.iteration(images, log=writer is not None)
             if first_iter and rank == 0:
                 first_iter = False
+                features = out['features']
+                images_discriminator = out['images_d']
                 fixed_features = [torch.clone(f) for f in features]
                 fixed_masks = [torch.ones(f.shape, device=device) for f in features]
                 fixed_features_diversity = [torch.clone(f) for f in features]
@@ -533,43 +670,12 @@ def _main():
                     orig_images_diversity[i] = orig_images_diversity[i % 8]
                 grid = imageio.make_grid(orig_images_diversity, padding=2, normalize=True, nrow=8)
                 imageio.save_image(grid, os.path.join(temp_results_dir, 'original_images_diversity.jpg'))
-            features_to_train = random.randint(1, len(features) - 2) if args.fixed_layer is None else args.fixed_layer
-            masks = [features[i].clone() for i in range(len(features))]
-            if train_type == 1:
-                setMasksPart1(masks, device, features_to_train)
-            else:
-                setMasksPart2(masks, device, features_to_train)
-            fake_images = fake_for_discriminator(generator, images.shape[0], features, masks)
-            pf.hand_over(images, images_discriminator, features, masks, fake_images)
-            z_g = fake_g = None
-            if iterations % args.discriminator_steps == 1 and pf.on:
-                # this iteration ends with a generator step: its forward does not depend on the critic step either
-                z_g = torch.randn(images.shape[0], 128, 1, 1, device=device)
-                fake_g = fake_for_generator(generator, features, masks, z_g)
-                pf.hand_over(z_g, fake_g)
-            pf.__exit__(None, None, None)
-            discriminator_loss_dict = train_discriminator(generator, discriminator, criterion_discriminator,
-                                                          discriminator_optimizer, images_discriminator, features, masks,
-                                                          fake_images=fake_images)
-            for k, v in discriminator_loss_dict.items():
-                pending.append(('D/%s' % k, iterations, v.detach()))
-                if iterations % 30 == 1:
-                    print('{}: {:.6f}'.format(k, v))
-            if iterations % args.discriminator_steps == 1:
-                generator_loss_dict = train_generator(generator, discriminator, criterion_generator, generator_optimizer,
-                                                      images.shape[0], features, criterion_features, features_to_train, classifier,
-                                                      normalizer_clf, criterion_diversity_n, criterion_diversity_d, masks, train_type,
-                                                      z=z_g, fake_images=fake_g)
-                for k, v in generator_loss_dict.items():
-                    pending.append(('G/%s' % k, iterations // 5 + 1, v.detach()))
-                    if iterations % 30 == 1:
-                        print('{}: {:.6f}'.format(k, v))
-            if writer is not None and (iterations % 30 == 1):          # flush scalars in batches: one sync per 30 iterations
-                for tag, step, v in pending:
-                    writer.add_scalar(tag, float(v), global_step=step)
-                pending = []
-            elif writer is None:
-                pending = []
+            if writer is not None and (iterations % 30 == 1):          # scalars leave the device in batches: one sync per 30 iterations
+                for it, scalars in loop.pop_logged():
+                    for tag, v in scalars.items():
+                        writer.add_scalar(tag, v, global_step=it if tag.startswith('D/') else it // 5 + 1)
+                        if it == iterations:
+                            print('{}: {:.6f}'.format(tag.split('/', 1)[1], v))
 
             if rank == 0 and iterations % 1000 == 1:
                 torch.save(generator.state_dict(), models_dir + '/' + args.model_name + 'G')
@@ -586,6 +692,7 @@ def _main():
                             fake_images = torch.vstack((fake_images, sample(generator, z, fixed_features, one_layer_mask)))
                             fake_images_diversity = torch.vstack((fake_images_diversity,
                                                                   sample(generator, z2, fixed_features_diversity, one_layer_mask)))
+                    generator.train()
                     grid = imageio.make_grid(fake_images, padding=2, normalize=True, nrow=8)
                     imageio.save_image(grid, os.path.join(temp_results_dir, 'res_iter_{}.jpg'.format(iterations // 1000)))
                     grid = imageio.make_grid(fake_images_diversity, padding=2, normalize=True, nrow=8)

@@ -1,0 +1,155 @@
+"""The captured loop body (loop.TrainLoop) against eager execution of the same body, and the order of its random draws.
+
+  * replay (sempyr_replay_launch: plain stream launches re-issued from native code) and hipGraphLaunch of the captured body
+    are BIT-identical to issuing the body from Python, over 7 iterations (two generator steps, every layer variant that the
+    seeded draws select), including `prepare()`'s throw-away warm-up runs being undone exactly;
+  * without injected noise the loop draws z (CPU generator), alpha and the generator step's z (device generator) in the
+    reference's order (train_model.py:128, :53, :90), and train type / layer / crop from Python's `random` in the
+    reference's order (:301, :327, :201)."""
+import random
+from argparse import Namespace
+
+import pytest
+import torch
+
+from oracle import masks as omasks
+from oracle import recipes
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(dev, use_graphs, executor='own', B=4, norm='instance_norm', gen_type='res', div=False, seed=11):
+    from semantic_pyramid_for_image_generation_amd import loop, optim
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    from semantic_pyramid_for_image_generation_amd.classifier import Classifier, resnet18
+    from semantic_pyramid_for_image_generation_amd.discriminator import Discriminator
+    from semantic_pyramid_for_image_generation_amd.generator import Generator
+    torch.manual_seed(seed)
+    G = Generator(gen_type); G.init_weights()
+    D = Discriminator(norm, gen_type); D.init_weights()
+    C = Classifier(resnet18(365)); C.load_state_dict(recipes.make_resnet(seed).state_dict())
+    G.to(dev); D.to(dev); C.to(dev).eval()
+    for p in C.parameters():
+        p.requires_grad_(False)
+    tm.args = Namespace(use_diversity_loss=div, gradient_penalty_weight=10.0)
+    g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
+    d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
+    return G, D, loop.TrainLoop(G, D, C, g_opt, d_opt, B, dev, use_graphs=use_graphs, executor=executor)
+
+
+def _run(dev, use_graphs, executor, iters, prepare, **kw):
+    G, D, lp = _make(dev, use_graphs, executor, **kw)
+    pool = [recipes.image_batch(40 + i, lp.B).to(dev) for i in range(3)]
+    if prepare:
+        lp.prepare()
+    torch.manual_seed(7); random.seed(7)
+    for i in range(iters):
+        lp.iteration(pool[i % 3], log=True)
+    logged = lp.pop_logged()
+    torch.cuda.synchronize()
+    state = {('G', k): v.detach().clone() for k, v in G.state_dict().items()}
+    state.update({('D', k): v.detach().clone() for k, v in D.state_dict().items()})
+    return logged, state, lp
+
+
+@pytest.mark.parametrize("executor", ["own", "hip"])
+def test_replay_bit_identical_to_eager(dev, executor):
+    le, se, _ = _run(dev, False, 'own', 7, False)
+    lg, sg, lp = _run(dev, True, executor, 7, True)
+    assert len(lp.graphs) == 8                                  # (generator step or not) x layer 1..4, all captured by prepare()
+    if executor == 'own':
+        stats = lp.graphs[(False, False, 1)].stats
+        assert stats[0] > 300 and stats[2] == 0 and stats[4] >= 2      # kernels; no memcpy nodes; more than one stream
+    assert [it for it, _ in le] == list(range(1, 8))
+    for (ia, a), (ib, b) in zip(le, lg):
+        assert ia == ib and a == b, (ia, a, b)
+    assert sum(1 for _, d in le if 'G/g_loss' in d) == 2        # iterations 1 and 6 end with a generator step
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
+
+
+def test_replay_without_prepare_captures_on_second_occurrence(dev):
+    """a variant runs eagerly when first met and is captured when met again: same results as all-eager"""
+    le, se, _ = _run(dev, False, 'own', 6, False, B=2, norm='layer_norm')
+    lg, sg, lp = _run(dev, True, 'own', 6, False, B=2, norm='layer_norm')
+    assert 1 <= len(lp.graphs) <= 5
+    assert [d for _, d in le] == [d for _, d in lg]
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
+
+
+def test_replay_batch_norm_critic_and_diversity(dev):
+    """BatchNorm critic (running statistics and num_batches_tracked are written by the replayed kernels) + diversity loss"""
+    le, se, _ = _run(dev, False, 'own', 6, False, B=2, norm='batch_norm', gen_type='default', div=True)
+    lg, sg, _ = _run(dev, True, 'own', 6, True, B=2, norm='batch_norm', gen_type='default', div=True)
+    assert [d for _, d in le] == [d for _, d in lg]
+    assert any('G/diversity loss' in d for _, d in le)
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
+    assert int(se[('D', 'conv_block1.conv_block1.block.1.num_batches_tracked')]) == 6 * 3 + 2     # 3 critic passes per D step + 1 per G step (iterations 1 and 6)
+
+
+def test_draw_order_matches_reference(dev):
+    G, D, lp = _make(dev, False, B=3)
+    images = recipes.image_batch(3, 3).to(dev)
+    torch.manual_seed(123); random.seed(123)
+    key1 = lp.draw()                                            # iteration 1: critic step + generator step
+    i1 = lp._draw_device(key1, images, static=False)
+    got1 = (i1.z_d.clone(), i1.alpha.clone(), i1.z_g.clone(), lp.train_type, lp.features_to_train, list(lp.specs))
+    key2 = lp.draw()                                            # iteration 2: critic step only
+    i2 = lp._draw_device(key2, images, static=True)
+    assert i2.z_g is lp.z_g
+    got2 = (i2.z_d.clone(), i2.alpha.clone(), lp.train_type, lp.features_to_train, list(lp.specs))
+    # the reference's order, written out
+    torch.manual_seed(123); rnd = random.Random(123)
+    shapes = recipes.tap_shapes(3)
+    is1, L1 = omasks.draw_iteration(rnd, 0.6)
+    m1, crop1 = omasks.masks_part2(shapes, L1, rnd)
+    z_d1 = torch.randn(3, 128, 1, 1)                            # train_model.py:128 (CPU generator)
+    alpha1 = torch.rand(3, 1, 1, 1, device=dev)                 # :53
+    z_g1 = torch.randn(3, 128, 1, 1, device=dev)                # :90
+    is2, L2 = omasks.draw_iteration(rnd, 0.6)
+    m2, crop2 = omasks.masks_part2(shapes, L2, rnd)
+    z_d2 = torch.randn(3, 128, 1, 1)
+    alpha2 = torch.rand(3, 1, 1, 1, device=dev)
+    assert key1 == (True, False, L1) and key2 == (False, False, L2)
+    assert torch.equal(got1[0].cpu(), z_d1) and torch.equal(got1[1], alpha1) and torch.equal(got1[2], z_g1)
+    assert torch.equal(got2[0].cpu(), z_d2) and torch.equal(got2[1], alpha2)
+    assert (got1[3] == 1) is False and got1[4] == L1 and got2[3] == L2
+    # the specs describe exactly the oracle's masks
+    from semantic_pyramid_for_image_generation_amd import ops
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    for specs, want in ((got1[5], m1), (got2[4], m2)):
+        masks = [torch.empty(s, device=dev) for s in shapes]
+        spec_dev = torch.empty(36, dtype=torch.int32, device=dev)
+        ops.store_words(spec_dev, tm.spec_words(specs))
+        ops.build_masks(masks, spec_dev)
+        for m, w in zip(masks, want):
+            assert torch.equal(m.cpu(), torch.from_numpy(w))
+
+
+def test_norm_is_twice_differentiable(dev):
+    """train_model.norm (reference train_model.py:58-60) composed by hand into the penalty, as the reference's one_mean_gp
+    does under create_graph=True: forward, backward and double backward against torch."""
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(4, 3, 8, 8, generator=g).to(dev)
+    w0 = torch.randn(4, 3, 8, 8, generator=g).to(dev)
+
+    def penalty(norm_fn):
+        x = x0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        y = (x * w).tanh()                                       # something with a graph, like d pred / d x
+        (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+        n = norm_fn(gx)
+        gp = ((n - 1) ** 2).mean()
+        gp.backward()
+        return n.detach(), gp.detach(), w.grad.detach()
+    n1, gp1, gw1 = penalty(tm.norm)
+    n0, gp0, gw0 = penalty(lambda t: t.view(t.size(0), -1).norm(p=2, dim=1))
+    assert torch.allclose(n1, n0, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gp1, gp0, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gw1, gw0, rtol=1e-4, atol=1e-6)
+    z = torch.zeros(2, 5, device=dev, requires_grad=True)       # zero rows: zero gradient, not NaN
+    tm.norm(z).sum().backward()
+    assert torch.equal(z.grad, torch.zeros_like(z))
