@@ -288,6 +288,17 @@ int sempyr_l1_mean_bwd(const float* a, const float* b, const float* mask, const 
  * rows*SEMPYR_GP_SPLIT floats): long rows of a small batch are reduced by SEMPYR_GP_SPLIT workgroups each. */
 #define SEMPYR_GP_SPLIT 48
 int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp, float* scratch, void* stream);
+/* sempyr_gp_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  Same results as sempyr_gp_fwd called with a
+ * scratch buffer, bit for bit, but the split partials live in a device array built into the library
+ * (SEMPYR_GP_STATIC_MAX_ROWS * SEMPYR_GP_SPLIT floats = 48 KB per GPU, held until the process ends): the caller passes
+ * inputs and outputs only, and the call performs no hipMalloc / hipFree (nor any allocating library routine).
+ * rows > SEMPYR_GP_STATIC_MAX_ROWS is rejected with SEMPYR_ERR_INVALID.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race -- serialise them.  Nothing in the array has to start at
+ * zero (each call overwrites every partial it later reads).  The first call on a device looks up the array's device
+ * address (hipGetSymbolAddress); make that first call outside stream capture. */
+#define SEMPYR_GP_STATIC_MAX_ROWS 256
+int sempyr_gp_fwd_static(const float* grad, int rows, int len, float* norms, float* gp, void* stream);
 /* out = grad * (*gout) * (2/rows) * (norm-1)/norm : its backward (feeds the double backward) */
 int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int rows, int len, float* out, void* stream);
 /* out[c] = scale * sum_{n,hw} x[n][c][hw] : conv bias gradient ; scratch = N*C floats ; accumulate != 0: out[c] += that */

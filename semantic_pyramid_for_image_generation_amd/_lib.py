@@ -104,6 +104,7 @@ SIGNATURES = {
     "sempyr_l1_mean": [_P, _P, _P, c_int64, _P, _P, _P],
     "sempyr_l1_mean_bwd": [_P, _P, _P, _P, c_int64, _P, _P, _P],
     "sempyr_gp_fwd": [_P, c_int, c_int, _P, _P, _P, _P],
+    "sempyr_gp_fwd_static": [_P, c_int, c_int, _P, _P, _P],
     "sempyr_gp_bwd": [_P, _P, _P, c_int, c_int, _P, _P],
     "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P],
     "sempyr_replay_create": [_P, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32)],

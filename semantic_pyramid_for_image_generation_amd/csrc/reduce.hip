@@ -2,6 +2,7 @@
 // WGAN means (train_model.py:39-46), masked L1 feature loss (train_model.py:212-222 with nn.L1Loss,
 // :270), diversity L1s (:109), per-sample L2 norm + (n-1)^2 penalty (:58-66), bias gradients.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -247,6 +248,51 @@ extern "C" int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms,
     hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(256), 0, st, norms, (const float*)scratch, split, rows, gp);
     SEMPYR_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- the one entry point that allocates nothing and takes no workspace (include/sempyr.h: sempyr_gp_fwd_static) ----------
+// The split partials live in a file-scope device array.  In host code `gp_static_scratch` is only a stand-in for the
+// symbol: its device address is looked up once per device (hipGetSymbolAddress, with that device current) and from then on
+// only that pointer is handed to kernels.  Every GPU holds its own copy of the array until the process ends.
+static __device__ __align__(256) float gp_static_scratch[SEMPYR_GP_STATIC_MAX_ROWS * SEMPYR_GP_SPLIT];
+
+namespace {
+constexpr int GP_MAX_DEVICES = 64;
+float* g_gp_scratch_ptr[GP_MAX_DEVICES];          // per device, set once (guarded by g_gp_scratch_lock)
+std::mutex g_gp_scratch_lock;
+
+int gp_static_scratch_ptr(float** out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { sempyr_set_error("gp_fwd_static: hipGetDevice: %s", hipGetErrorString(e)); return (int)e; }
+    if (dev < 0 || dev >= GP_MAX_DEVICES) SEMPYR_FAIL("gp_fwd_static: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_gp_scratch_lock);
+    if (!g_gp_scratch_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(gp_static_scratch));
+        if (e != hipSuccess || !p) {
+            sempyr_set_error("gp_fwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : SEMPYR_ERR_INVALID;
+        }
+        g_gp_scratch_ptr[dev] = p;
+    }
+    *out = g_gp_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" int sempyr_gp_fwd_static(const float* grad, int rows, int len, float* norms, float* gp, void* stream)
+{
+    if (!grad || !norms || !gp || rows < 1 || len < 1) SEMPYR_FAIL("gp_fwd_static: bad arguments");
+    if (rows > SEMPYR_GP_STATIC_MAX_ROWS)
+        SEMPYR_FAIL("gp_fwd_static: %d rows exceed the built-in scratch (SEMPYR_GP_STATIC_MAX_ROWS = %d); use sempyr_gp_fwd "
+                    "with a caller-provided scratch buffer", rows, SEMPYR_GP_STATIC_MAX_ROWS);
+    float* scratch = nullptr;
+    const int rc = gp_static_scratch_ptr(&scratch);
+    if (rc != 0) return rc;
+    // every partial that gp_final_kernel reads is written by the row kernel of the same call: nothing has to start at zero
+    return sempyr_gp_fwd(grad, rows, len, norms, gp, scratch, stream);
 }
 
 extern "C" int sempyr_gp_bwd(const float* grad, const float* norms, const float* gout, int rows, int len,
