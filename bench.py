@@ -97,6 +97,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
+    ap.add_argument('--profile-pass', action='store_true',
+                    help='run ONLY the single-stream instrumented pass of --steps cycles, bracketed by sempyr_marker_kernel launches '
+                         '(for rocprofv3 --kernel-trace; SEMPYR_PROFILE_DUMP=<csv> keeps the per-launch shapes, see tools/roofline_table.py)')
     ap.add_argument('--loop-mode', default=os.environ.get('SEMPYR_LOOP_MODE', 'eager'), choices=['eager', 'replay', 'hipgraph'],
                     help='eager: the body is issued from Python on four streams; replay: captured once per variant and re-issued by '
                          'sempyr_replay_launch; hipgraph: captured and replayed by hipGraphLaunch')
@@ -148,6 +151,25 @@ def main():
     for _ in range(a.warmup):
         cycle()
     timing = not a.no_kernel_timing
+    if a.profile_pass:
+        ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = ops.PREFETCH = False
+        lp.use_graphs = False
+        cycle()
+        barrier()
+        kms, kl, kf = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+        raw = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib.sempyr_profile_begin(4096 * max(a.steps, 1)), "sempyr_profile_begin")
+        _lib.check(_lib.lib.sempyr_profile_marker(1, raw), "sempyr_profile_marker")
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            cycle()
+        _lib.check(_lib.lib.sempyr_profile_marker(2, raw), "sempyr_profile_marker")
+        barrier()
+        el = time.perf_counter() - t1
+        _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
+        print(json.dumps({"profile_pass": True, "steps": a.steps, "ms_per_step_single_stream": 1e3 * el / a.steps,
+                          "conv_launches": int(kl.value), "conv_ms_hip_events": kms.value, "conv_gflop_2MNK": kf.value * 1e-9}), flush=True)
+        return
     barrier()
     c0 = time.process_time()
     t0 = time.perf_counter()

@@ -102,11 +102,21 @@ int sempyr_conv2d_pack_weights_many(const sempyr_pack_item* items, int n_items, 
  * x2 upsample (the 1x1 skip branch of an upsampling block computed before the upsample, generator.py:44,60-62). act is a SEMPYR_ACT_* code applied in the
  * kernel epilogue (`conv -> LeakyReLU` of the critic stem discriminator.py:106-107, `conv -> Tanh` of the generator head
  * generator.py:116-120), slope the LeakyReLU slope. y_pooled (optional, [B,Cout,Ho/2,Wo/2]) also receives
- * AvgPool2d(2)(y) (discriminator.py:109), computed in the same epilogue when the launch is a single pass. */
+ * AvgPool2d(2)(y) (discriminator.py:109), computed in the same epilogue when the launch is a single pass.
+ * The critic stem (conv -> LeakyReLU -> AvgPool2d, discriminator.py:106-109) never needs its full-resolution activation
+ * again except for the SIGN of every element (LeakyReLU's derivative), so with the fused pooled epilogue (single pass,
+ * Cout > 4, Ho*Wo a multiple of 32; otherwise rejected):
+ *   act_bits (optional, out, B*Cout*Ho*Wo/32 words): bit = 1 where the activated output is > 0, in "quad" pixel order
+ *     (bit 4c+2a+b of plane (b, m) is fine pixel (2h+a, 2w+b) of coarse pixel c = h*(Wo/2)+w); y may then be NULL -- the
+ *     268 MB activation of a 16-image batch is not written at all, 8.4 MB of bits are;
+ *   mask_bits (optional, in, same layout; bias NULL, act NONE): the convolution's result is multiplied by
+ *     (bit ? 1 : slope) before the pool, y NULL: the double backward of that stem (gradient penalty,
+ *     train_model.py:69-76) as one launch instead of conv + full-resolution round trip + pool. */
 int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wpacked_fwd,
                       const int32_t* ktab_fwd_dev, const float* bias, const float* scale, const float* res,
                       int res_half, int act, float slope, float* y,
-                      float* y_pooled, void* workspace, size_t workspace_bytes, void* stream);
+                      float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a
  * ConvTranspose2d whose forward this is). With ups=1 the result is the gradient in the upsampled
@@ -257,15 +267,16 @@ int sempyr_lerp_rows(const float* real, const float* fake, const float* alpha_ro
 int sempyr_normalize(const float* x, const float* mean_c, const float* std_c, float* y,
                      int N, int C, int HW, int backward, void* stream);
 /* y[r][h][w] = scale*sum 2x2 : nn.AvgPool2d(2) (scale .25) discriminator.py:57,103 ; upsample backward (scale 1).
- * yref (optional, fine resolution, output of a ReLU/LeakyReLU): every x is first multiplied by act'(yref). */
-int sempyr_pool2_down(const float* x, const float* yref, float* y, int rows, int H, int W, float scale,
+ * yref (optional, fine resolution, output of a ReLU/LeakyReLU): every x is first multiplied by act'(yref).
+ * act_bits (optional, instead of yref): the sign bits sempyr_conv2d_fwd wrote for that output. */
+int sempyr_pool2_down(const float* x, const float* yref, const uint32_t* act_bits, float* y, int rows, int H, int W, float scale,
                       int act, float slope, void* stream);
 /* y[r][2h+a][2w+b] = scale*x[r][h][w] : nn.UpsamplingNearest2d(2) generator.py:44 ; avg-pool backward (scale .25).
  * yref (optional, fine resolution): the result is multiplied by act'(yref) -- the backward of
  * `LeakyReLU -> AvgPool2d` (discriminator.py:107-109) in one pass. row_partials (optional, [rows][h*w/512] floats, needs
  * h*w % 512 == 0): partial sums of y per row, so the bias gradient of the conv in front (a channel sum of y) needs no second
- * pass over the full-resolution tensor. */
-int sempyr_pool2_up(const float* x, const float* yref, float* y, int rows, int h, int w, float scale,
+ * pass over the full-resolution tensor. act_bits (optional, instead of yref): sign bits as for sempyr_pool2_down. */
+int sempyr_pool2_up(const float* x, const float* yref, const uint32_t* act_bits, float* y, int rows, int h, int w, float scale,
                     int act, float slope, float* row_partials, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the ResNet18 stem classifier.py:36 ; idx = argmax offsets for the backward */
 int sempyr_maxpool3s2_fwd(const float* x, float* y, int32_t* idx, int rows, int H, int W, void* stream);
@@ -326,6 +337,8 @@ int sempyr_replay_destroy(sempyr_replay* plan);
  * the summed kernel time, the launch count and the algorithmic FLOPs (2*M*N*K) of those launches.
  * ---------------------------------------------------------------------------------------- */
 int sempyr_profile_begin(int max_launches);
+/* launches the do-nothing kernel `sempyr_marker_kernel` on `stream`: brackets a region in a rocprofv3 kernel trace */
+int sempyr_profile_marker(int tag, void* stream);
 int sempyr_profile_end(double* kernel_ms, int64_t* launches, double* flops);
 
 #ifdef __cplusplus

@@ -68,7 +68,7 @@ SIGNATURES = {
     "sempyr_conv2d_tables": [_DESC, c_int, _P, _P],
     "sempyr_conv2d_pack_weights": [_DESC, c_int, _P, _P, _P, _P],
     "sempyr_conv2d_pack_weights_many": [ctypes.POINTER(PackItem), c_int, _P],
-    "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P],
+    "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, _P, c_size_t, _P],
     "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P],
@@ -94,8 +94,8 @@ SIGNATURES = {
     "sempyr_accumulate_many": [ctypes.POINTER(AccumItem), c_int, _P],
     "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],
     "sempyr_normalize": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
-    "sempyr_pool2_down": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
-    "sempyr_pool2_up": [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P],
+    "sempyr_pool2_down": [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
+    "sempyr_pool2_up": [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P],
     "sempyr_maxpool3s2_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "sempyr_maxpool3s2_bwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "sempyr_reduce_scratch_floats": [],
@@ -111,6 +111,7 @@ SIGNATURES = {
     "sempyr_replay_launch": [_P, _P],
     "sempyr_replay_destroy": [_P],
     "sempyr_profile_begin": [c_int],
+    "sempyr_profile_marker": [c_int, _P],
     "sempyr_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
 }
 

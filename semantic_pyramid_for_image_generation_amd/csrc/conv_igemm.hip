@@ -106,6 +106,10 @@ struct IgemmParams {
     int act; float slope;  // GATHER epilogue activation (applied with the bias, only when splits == 1)
     int PR, PW, CW;        // patch kernel: patch rows / columns (source pixels), tile width in output pixels
     float* Pool; int quad; // fused AvgPool2d(2) of the (activated) output: pooled tensor, quad pixel order on
+    // quad mode only. Bits (out): one bit per output element, 1 = activated value > 0, in quad pixel order
+    // [b][m][OHW/32 words] -- all a ReLU-family backward needs of the full-resolution activation (1/32 of its bytes).
+    // MaskBits (in): the accumulator is multiplied by act'(bit) before pooling (the double backward of that stem).
+    uint32_t* Bits; const uint32_t* MaskBits;
 };
 
 // UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
@@ -470,11 +474,22 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
             if (p.quad) {                                       // uniform: 2x2 window = lanes 4q..4q+3 (N % 4 == 0)
                 float* pp = p.Pool + (size_t)b * (p.OCHW >> 2) + (qy >> 1) * (p.OW >> 1) + (qx >> 1);
                 const bool lead = (n & 3) == 0;
+                const int wpp = p.OHW >> 5;                     // bit words per plane; this half-wave's 32 pixels are one word
+                const size_t wbase = (size_t)b * p.M * wpp + ((n - b * pQHW) >> 5);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
 #pragma unroll
                     for (int r16 = 0; r16 < 16; ++r16) {
+                        const int mrow = mb + (r16 & 3) + 8 * (r16 >> 2);
+                        if (p.Bits) {                           // uniform
+                            const unsigned long long bal = __builtin_amdgcn_ballot_w64(acc[i][j][r16] > 0.f);
+                            if (l31 == 0 && mrow < p.M) p.Bits[wbase + (size_t)mrow * wpp] = kh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                        }
+                        if (p.MaskBits) {                       // uniform
+                            const uint32_t wd = p.MaskBits[wbase + (size_t)(mrow < p.M ? mrow : 0) * wpp];
+                            acc[i][j][r16] *= ((wd >> l31) & 1u) ? 1.f : p.slope;
+                        }
                         float v = acc[i][j][r16];
                         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
                         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
@@ -483,6 +498,7 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
                     }
                 }
             }
+            if (!p.Out) continue;                               // uniform: pooled output (+ sign bits) only
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
@@ -1767,11 +1783,11 @@ static int run_splitk_reduce(const float* slabs, float* out, const float* bias, 
 extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
                                  const int32_t* ktab, const float* bias, const float* scale, const float* res,
                                  int res_half, int act, float slope, float* y,
-                                 float* y_pooled, void* ws, size_t ws_bytes, void* stream)
+                                 float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits, void* ws, size_t ws_bytes, void* stream)
 {
     sempyr_conv_plan pl;
     if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_FWD, &pl)) return rc;
-    if (!x || !wp || !ktab || !y) SEMPYR_FAIL("conv fwd: null pointer");
+    if (!x || !wp || !ktab || (!y && !y_pooled)) SEMPYR_FAIL("conv fwd: null pointer");
     if (act < SEMPYR_ACT_NONE || act > SEMPYR_ACT_TANH) SEMPYR_FAIL("conv fwd: bad activation %d", act);
     if ((size_t)pl.workspace_bytes > ws_bytes || (pl.workspace_bytes && !ws))
         SEMPYR_FAIL("conv fwd: workspace too small (%zu < %lld)", ws_bytes, (long long)pl.workspace_bytes);
@@ -1800,6 +1816,15 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     if (y_pooled && act == SEMPYR_ACT_TANH) SEMPYR_FAIL("conv fwd: pooled output is defined for ReLU-family activations");
     const bool fused_pool = y_pooled && splits == 1 && d->Cout > 4;          // MFMA single-pass launch: pool in the epilogue
     if (fused_pool) { p.Pool = y_pooled; p.quad = 1; }
+    if (act_bits || mask_bits || !y) {
+        if (!fused_pool || (pl.Ho * pl.Wo) % 32 != 0)
+            SEMPYR_FAIL("conv fwd: sign bits / a pooled-only output need the fused pooled epilogue (single pass, Cout > 4, Ho*Wo %% 32 == 0); "
+                        "check sempyr_conv2d_plan().splits");
+        if (act_bits && !(act == SEMPYR_ACT_RELU || act == SEMPYR_ACT_LRELU)) SEMPYR_FAIL("conv fwd: sign bits are defined for ReLU / LeakyReLU");
+        if (mask_bits && (act != SEMPYR_ACT_NONE || bias || act_bits)) SEMPYR_FAIL("conv fwd: mask bits replace bias / activation / sign-bit output");
+        p.Bits = act_bits; p.MaskBits = mask_bits;
+        if (mask_bits) p.slope = slope;
+    }
     int rc = 0;
     if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) rc = launch_rgb3x3(p, st);
     else {
@@ -1811,7 +1836,7 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     if (splits > 1)
         if ((rc = run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st, scale, res, res_half ? pl.Wo : 0))) return rc;
     if (y_pooled && !fused_pool)
-        return sempyr_pool2_down(y, nullptr, y_pooled, d->B * d->Cout, pl.Ho, pl.Wo, 0.25f, SEMPYR_ACT_NONE, 0.f, stream);
+        return sempyr_pool2_down(y, nullptr, nullptr, y_pooled, d->B * d->Cout, pl.Ho, pl.Wo, 0.25f, SEMPYR_ACT_NONE, 0.f, stream);
     return 0;
 }
 
@@ -1958,6 +1983,16 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
 // ------------------------------------------------------------------------------------------
 // kernel-timing hooks (measurement only; never enabled by the product path)
 // ------------------------------------------------------------------------------------------
+// a named do-nothing kernel: brackets the timed region in a rocprofv3 kernel trace (tools/roofline_table.py)
+extern "C" __global__ void sempyr_marker_kernel(int tag) { (void)tag; }
+
+extern "C" int sempyr_profile_marker(int tag, void* stream)
+{
+    hipLaunchKernelGGL(sempyr_marker_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tag);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sempyr_profile_begin(int max_launches)
 {
     if (max_launches < 1) SEMPYR_FAIL("profile_begin: max_launches must be positive");

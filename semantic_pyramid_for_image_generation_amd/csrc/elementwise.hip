@@ -227,9 +227,12 @@ __global__ __launch_bounds__(256) void pool2_up_kernel(const float* __restrict__
 // Two coarse pixels per thread (w even, 16-byte aligned tensors): every fine-resolution access is a float4
 // `partials` (optional): sum of the workgroup's outputs, one float per workgroup (= [row][h*w/512] when a plane is a whole
 // number of workgroups) -- the per-row sums of the result (a conv bias gradient) without reading it back.
+// `bits` (instead of yref): the sign bits the fused stem convolution wrote (conv_igemm.hip, quad pixel order): the pair of
+// coarse pixels of thread i owns byte i of the bit array -- bit 4c+2a+b is fine pixel (2h+a, 2w+b) of coarse pixel c.
 __global__ __launch_bounds__(256) void pool2_up_v2_kernel(const float* __restrict__ x, const float* __restrict__ yref,
                                                           float* __restrict__ y, long long total_pairs, int h, int w2,
-                                                          float scale, int act, float slope, float* __restrict__ partials)
+                                                          float scale, int act, float slope, float* __restrict__ partials,
+                                                          const unsigned char* __restrict__ bits)
 {
     __shared__ float sh[4];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -247,6 +250,11 @@ __global__ __launch_bounds__(256) void pool2_up_v2_kernel(const float* __restric
         a.z *= act_deriv_y(ya.z, act, slope); a.w *= act_deriv_y(ya.w, act, slope);
         b.x *= act_deriv_y(yb.x, act, slope); b.y *= act_deriv_y(yb.y, act, slope);
         b.z *= act_deriv_y(yb.z, act, slope); b.w *= act_deriv_y(yb.w, act, slope);
+    } else if (bits) {
+        const unsigned m = bits[i];
+        const float lo = (act == SEMPYR_ACT_LRELU) ? slope : 0.f;
+        a.x *= (m & 1u) ? 1.f : lo;  a.y *= (m & 2u) ? 1.f : lo;  b.x *= (m & 4u) ? 1.f : lo;  b.y *= (m & 8u) ? 1.f : lo;
+        a.z *= (m & 16u) ? 1.f : lo; a.w *= (m & 32u) ? 1.f : lo; b.z *= (m & 64u) ? 1.f : lo; b.w *= (m & 128u) ? 1.f : lo;
     }
     *reinterpret_cast<float4*>(y + off) = a;
     *reinterpret_cast<float4*>(y + off + 4 * w2) = b;
@@ -258,7 +266,8 @@ __global__ __launch_bounds__(256) void pool2_up_v2_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void pool2_down_v2_kernel(const float* __restrict__ x, const float* __restrict__ yref,
                                                             float* __restrict__ y, long long total_pairs, int h, int w2,
-                                                            float scale, int act, float slope)
+                                                            float scale, int act, float slope,
+                                                            const unsigned char* __restrict__ bits)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total_pairs) return;
@@ -274,6 +283,11 @@ __global__ __launch_bounds__(256) void pool2_down_v2_kernel(const float* __restr
         a.z *= act_deriv_y(ya.z, act, slope); a.w *= act_deriv_y(ya.w, act, slope);
         b.x *= act_deriv_y(yb.x, act, slope); b.y *= act_deriv_y(yb.y, act, slope);
         b.z *= act_deriv_y(yb.z, act, slope); b.w *= act_deriv_y(yb.w, act, slope);
+    } else if (bits) {                                  // sign bits of the fused stem convolution (see pool2_up_v2_kernel)
+        const unsigned m = bits[i];
+        const float lo = (act == SEMPYR_ACT_LRELU) ? slope : 0.f;
+        a.x *= (m & 1u) ? 1.f : lo;  a.y *= (m & 2u) ? 1.f : lo;  b.x *= (m & 4u) ? 1.f : lo;  b.y *= (m & 8u) ? 1.f : lo;
+        a.z *= (m & 16u) ? 1.f : lo; a.w *= (m & 32u) ? 1.f : lo; b.z *= (m & 64u) ? 1.f : lo; b.w *= (m & 128u) ? 1.f : lo;
     }
     reinterpret_cast<float2*>(y)[i] = make_float2(scale * ((a.x + a.y) + (b.x + b.y)), scale * ((a.z + a.w) + (b.z + b.w)));
 }
@@ -532,33 +546,41 @@ extern "C" int sempyr_normalize(const float* x, const float* mean_c, const float
     return 0;
 }
 
-extern "C" int sempyr_pool2_down(const float* x, const float* yref, float* y, int rows, int H, int W, float scale,
-                                 int act, float slope, void* stream)
+extern "C" int sempyr_pool2_down(const float* x, const float* yref, const uint32_t* act_bits, float* y, int rows, int H, int W,
+                                 float scale, int act, float slope, void* stream)
 {
+    if (act_bits && (yref || !(act == SEMPYR_ACT_RELU || act == SEMPYR_ACT_LRELU) || (W & 3) || ((long long)H * W) % 32 != 0))
+        SEMPYR_FAIL("pool2_down: sign bits replace yref, for ReLU / LeakyReLU planes of a multiple of 32 elements and W %% 4 == 0");
     if (!x || !y || rows < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) SEMPYR_FAIL("pool2_down: bad arguments (H=%d W=%d)", H, W);
     if ((((uintptr_t)x | (uintptr_t)yref) & 7) != 0) SEMPYR_FAIL("pool2_down: inputs must be 8-byte aligned");
     if (act < 0 || act > 3) SEMPYR_FAIL("pool2_down: bad activation %d", act);
     const long long total = (long long)rows * (H / 2) * (W / 2);
     if ((W & 3) == 0 && ((((uintptr_t)x | (uintptr_t)yref) & 15) == 0) && (((uintptr_t)y & 7) == 0)) {
-        LAUNCH_1D(pool2_down_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, H / 2, W / 4, scale, act, slope);
+        LAUNCH_1D(pool2_down_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, H / 2, W / 4, scale, act, slope,
+                  (const unsigned char*)act_bits);
         return 0;
     }
+    if (act_bits) SEMPYR_FAIL("pool2_down: sign bits need 16-byte aligned tensors");
     LAUNCH_1D(pool2_down_kernel, total, (hipStream_t)stream, x, yref, y, total, H / 2, W / 2, scale, act, slope);
     return 0;
 }
 
-extern "C" int sempyr_pool2_up(const float* x, const float* yref, float* y, int rows, int h, int w, float scale,
-                               int act, float slope, float* row_partials, void* stream)
+extern "C" int sempyr_pool2_up(const float* x, const float* yref, const uint32_t* act_bits, float* y, int rows, int h, int w,
+                               float scale, int act, float slope, float* row_partials, void* stream)
 {
+    if (act_bits && (yref || !(act == SEMPYR_ACT_RELU || act == SEMPYR_ACT_LRELU) || (w & 1) || ((long long)h * w) % 8 != 0))
+        SEMPYR_FAIL("pool2_up: sign bits replace yref, for ReLU / LeakyReLU planes of a multiple of 32 fine elements and even w");
     if (!x || !y || rows < 1 || h < 1 || w < 1) SEMPYR_FAIL("pool2_up: bad arguments");
     if ((((uintptr_t)y | (uintptr_t)yref) & 7) != 0) SEMPYR_FAIL("pool2_up: output / yref must be 8-byte aligned");
     if (act < 0 || act > 3) SEMPYR_FAIL("pool2_up: bad activation %d", act);
     const long long total = (long long)rows * h * w;
     if ((w & 1) == 0 && ((((uintptr_t)y | (uintptr_t)yref) & 15) == 0) && (((uintptr_t)x & 7) == 0)) {
         if (row_partials && ((long long)h * w) % 512 != 0) SEMPYR_FAIL("pool2_up: row partials need h*w to be a multiple of 512");
-        LAUNCH_1D(pool2_up_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, h, w / 2, scale, act, slope, row_partials);
+        LAUNCH_1D(pool2_up_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, h, w / 2, scale, act, slope, row_partials,
+                  (const unsigned char*)act_bits);
         return 0;
     }
+    if (act_bits) SEMPYR_FAIL("pool2_up: sign bits need 16-byte aligned tensors");
     if (row_partials) SEMPYR_FAIL("pool2_up: row partials need an even width and 16-byte aligned tensors");
     LAUNCH_1D(pool2_up_kernel, total, (hipStream_t)stream, x, yref, y, total, h, w, scale, act, slope);
     return 0;

@@ -4,9 +4,13 @@ kernels.  The nearest-x2 upsample of the residual blocks is fused into the gathe
 convolutions instead of being materialised (reference generator.py:51-52,85)."""
 import torch.nn as nn
 
+import os
+
 from . import ops
 from .blocks import (init_weights, run_conv, run_conv_norm, run_conv_norm_act,  # noqa: F401  (init_weights re-exported)
-                     run_norm_add_norm_act, tail_takes_half_res, fuses_conv_norm, _single)
+                     run_norm, run_norm_add_norm_act, tail_takes_half_res, fuses_conv_norm, activation_kind, _single)
+
+ZERO_SKIP = os.environ.get("SEMPYR_ZERO_SKIP", "1") != "0"
 
 
 class ConvBlock(nn.Module):
@@ -86,10 +90,22 @@ class GeneratorBlock(nn.Module):
                 self.upsample = nn.UpsamplingNearest2d(scale_factor=2)
                 self.features_conv_block = ConvBlock(in_channels, out_channels, 3, conv_type='conv')
 
-    def forward(self, gen, features):
+    def forward(self, gen, features=None, mask=None):
+        """`mask` (optional): the feature mask of this level; the block then applies it itself (generator.py:126-129) and,
+        when the mask is tagged all-zero by the mask setters (every level at or above the selected layer, quirk Q2), does
+        not convolve the zeros: the convolution's output is zeros, the BatchNorm / ReLU behind it run as always."""
         gen = self.conv_block1(gen)
         if not self.with_features:
             return gen
+        block = self.features_conv_block.block
+        if mask is not None:
+            if (ZERO_SKIP and getattr(mask, '_sempyr_all_zero', False) and block[0].bias is None
+                    and isinstance(block[1], nn.BatchNorm2d) and block[1].training):
+                B, _, H, W = features.shape
+                y = ops.zero_conv_output(block[0].weight, (B, block[0].out_channels, 2 * H, 2 * W))
+                kind, slope = activation_kind(block[2])
+                return ops.add_act(gen, run_norm(block[1], y, kind, slope))
+            features = ops.mul(features, mask)
         features = self.features_conv_block(features, upsample=(self.gen_type == 'res'))
         return ops.add_act(gen, features)
 
@@ -123,7 +139,7 @@ class Generator(nn.Module):
         x = self.conv_block1(noise)
         x = self.conv_block2(x)
         for level, block in ((4, self.conv_block3), (3, self.conv_block4), (2, self.conv_block5), (1, self.conv_block6)):
-            x = block(x, ops.mul(features[level], masks[level]))
+            x = block(x, features[level], masks[level])
         if self.gen_type == 'res':
             x = self.conv_block7(x)
         return run_conv(self.last_conv, x, act_kind=ops.ACT_TANH)

@@ -490,16 +490,27 @@ def _workspace(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None, scale_ptr=0, res=None, res_half=False):
-    """`bias` is a tensor or a raw device address (the shift row of cached BatchNorm coefficients)."""
+def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None, scale_ptr=0, res=None, res_half=False,
+                  bits=None, mask_bits=None, want_y=True):
+    """`bias` is a tensor or a raw device address (the shift row of cached BatchNorm coefficients).  `bits` (out) /
+    `mask_bits` (in): the sign bits of the fused pooled epilogue (see sempyr_conv2d_fwd); want_y=False: pooled output only."""
     mp = plan.mode(CONV_FWD)
     wp = _packed_weights(plan, w, CONV_FWD)
-    y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device)
+    y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device) if want_y else None
     ws = _workspace(mp.ws_bytes, x.device)
     check(L.sempyr_conv2d_fwd(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(),
                               bias if isinstance(bias, int) else _p(bias), scale_ptr, _p(res), 1 if res_half else 0, act_kind, slope,
-                              y.data_ptr(), _p(pooled), _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
+                              _p(y), _p(pooled), _p(bits), _p(mask_bits), _p(ws), mp.ws_bytes, _stream()), "sempyr_conv2d_fwd")
     return y
+
+
+_STEM_BITS = os.environ.get("SEMPYR_STEM_BITS", "1") != "0"
+
+
+def _pooled_bits_ok(plan, act_kind):
+    """True when conv -> ReLU-family activation -> AvgPool2d(2) can keep sign bits instead of the full-resolution output."""
+    return (_STEM_BITS and act_kind in (ACT_RELU, ACT_LRELU) and plan.Cout > 4 and (plan.Ho * plan.Wo) % 32 == 0
+            and plan.Ho % 2 == 0 and plan.Wo % 4 == 0 and plan.mode(CONV_FWD).info.splits[0] <= 1)
 
 
 def _raw_conv_dgrad(plan, gy, w, bias):
@@ -552,15 +563,19 @@ class _ConvFwd(Function):
             bias = _req(bias, "conv bias")
         if act_kind == ACT_TANH and pool:
             raise _lib.SempyrError("conv2d: pooled output needs a ReLU-family (or no) activation")
-        out = None
+        out = bits = None
         if pool:
             out = torch.empty((plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2), dtype=torch.float32, device=x.device)
-        y = _raw_conv_fwd(plan, x, w, bias, act_kind, slope, out)
-        ctx.save_for_backward(x, w, y if act_kind != ACT_NONE else None, bias)
+            if _pooled_bits_ok(plan, act_kind):
+                # the backward only needs the SIGN of the full-resolution activation: 1 bit instead of 4 bytes per element
+                bits = torch.empty(plan.B * plan.Cout * plan.Ho * plan.Wo // 32, dtype=torch.int32, device=x.device)
+        y = _raw_conv_fwd(plan, x, w, bias, act_kind, slope, out, bits=bits, want_y=bits is None)
+        ctx.save_for_backward(x, w, bits if bits is not None else (y if act_kind != ACT_NONE else None), bias)
         ctx.plan = plan
         ctx.has_bias = bias is not None
         ctx.act = (act_kind, slope)
         ctx.pool = pool
+        ctx.bits = bits is not None
         return out if pool else y
 
     @staticmethod
@@ -573,13 +588,18 @@ class _ConvFwd(Function):
         bsrc = None               # what the bias gradient is the channel sum of (default: gy itself)
         if ctx.pool:
             h, wd = gy.shape[2], gy.shape[3]
+            yref, bits = (None, y) if ctx.bits else (y, None)
+            if ctx.bits and ctx.needs_input_grad[0] and not (want_w or want_b):
+                # input gradient only (gradient penalty's inner pass, generator step): one Function whose own backward
+                # (the penalty's double backward) is a single fused launch
+                return _apply(_StemInputGrad, gy, w, bits, plan, *ctx.act), None, None, None, None, None, None
             if want_b and not torch.is_grad_enabled() and (h * wd) % 512 == 0 and wd % 2 == 0 and y.data_ptr() % 16 == 0:
                 # the un-pool pass also emits per-row partial sums: the bias gradient needs no second pass over the
                 # full-resolution gradient
                 bsrc = torch.empty((gy.shape[0], gy.shape[1], (h * wd) // 512), dtype=torch.float32, device=gy.device)
-                gy = _pool2_up_raw(_req(gy, "grad"), 0.25, y, *ctx.act, partials=bsrc)
+                gy = _pool2_up_raw(_req(gy, "grad"), 0.25, yref, *ctx.act, partials=bsrc, bits=bits)
             else:
-                gy = _apply(_Pool2Up, gy, 0.25, y, *ctx.act)
+                gy = _apply(_Pool2Up, gy, 0.25, yref, ctx.act[0], ctx.act[1], bits)
         elif y is not None:
             gy = _apply(_ActBwd, gy, y, *ctx.act)
         gx = gw = gb = None
@@ -594,6 +614,42 @@ class _ConvFwd(Function):
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(gy, w, plan)
         return gx, gw, gb, None, None, None, None
+
+
+class _StemInputGrad(Function):
+    """gx = conv_transpose(0.25 * up2(g) * act'(bits), w): the input gradient of `conv -> ReLU-family act -> AvgPool2d(2)` given the
+    gradient g of the POOLED output and the sign bits of the activation.  Its backward (the gradient penalty's double
+    backward through the critic stem) is one launch: conv(u, w) masked by the bits and pooled in the epilogue -- the
+    full-resolution intermediate is never written."""
+
+    @staticmethod
+    def forward(ctx, g, w, bits, plan, act_kind, slope):
+        g = _req(g, "grad"); w = _req(w, "conv weight")
+        gz = _pool2_up_raw(g, 0.25, None, act_kind, slope, bits=bits)
+        gx = _raw_conv_dgrad(plan.noups(), gz, w, None)
+        ctx.save_for_backward(gz, w, bits)
+        ctx.plan = plan
+        ctx.act = (act_kind, slope)
+        return gx
+
+    @staticmethod
+    def backward(ctx, u):
+        gz, w, bits = ctx.saved_tensors
+        plan = ctx.plan
+        act_kind, slope = ctx.act
+        if torch.is_grad_enabled() and u.requires_grad:
+            raise NotImplementedError("third-order derivatives through the critic stem are not part of the hot path")
+        u = _req(u, "double-backward grad")
+        g_g = g_w = None
+        if not _INPUT_GRADS_ONLY and ctx.needs_input_grad[1]:
+            if _can_async(w, None, True, False):
+                _param_grads_async(gz, u, plan, w, None, True, False)
+            else:
+                g_w = _raw_conv_wgrad(plan, gz, u)
+        if ctx.needs_input_grad[0]:
+            g_g = torch.empty((plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2), dtype=torch.float32, device=u.device)
+            _raw_conv_fwd(plan, u, w, None, ACT_NONE, slope if act_kind == ACT_LRELU else 0.0, g_g, mask_bits=bits, want_y=False)
+        return g_g, g_w, None, None, None, None
 
 
 def _conv_input_grad(gy, w, plan):
@@ -674,6 +730,37 @@ def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NO
     if pool and (plan.Ho % 2 or plan.Wo % 2):
         raise _lib.SempyrError("conv2d: pooled output needs even output height and width")
     return _apply(_ConvFwd, x, w, bias, plan, act_kind, slope, pool)
+
+
+class _ZeroConv(Function):
+    """The output of a bias-free convolution whose input is known to be all zeros: zeros, with a zero weight gradient.
+    (The reference multiplies the classifier taps by masks that are all-zero for every level at or above the selected
+    layer -- quirk Q2 -- and convolves the zeros; train_model.py:197-209, generator.py:126-129.)"""
+
+    @staticmethod
+    def forward(ctx, w, shape):
+        w = _req(w, "conv weight")
+        y = torch.empty(shape, dtype=torch.float32, device=w.device)
+        check(L.sempyr_fill_const(y.data_ptr(), 0.0, y.numel(), _stream()), "sempyr_fill_const")
+        ctx.wshape = tuple(w.shape)
+        ctx.w_ref = _weak(w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.needs_input_grad[0] or _INPUT_GRADS_ONLY:
+            return None, None
+        w = ctx.w_ref()
+        gw = torch.empty(ctx.wshape, dtype=torch.float32, device=gy.device)
+        check(L.sempyr_fill_const(gw.data_ptr(), 0.0, gw.numel(), _stream()), "sempyr_fill_const")
+        if w is not None and _stash(w, gw):
+            return None, None
+        return gw, None
+
+
+def zero_conv_output(w, shape):
+    """conv(zeros, w) for a bias-free convolution: see _ZeroConv."""
+    return _apply(_ZeroConv, w, tuple(shape))
 
 
 def conv_transpose2d(x, w, bias=None, stride=1, padding=0):
@@ -1145,28 +1232,29 @@ class _Pool2Down(Function):
     """y = scale * sum_2x2 (x * act'(yref)); yref = None: plain 2x2 sum."""
 
     @staticmethod
-    def forward(ctx, x, scale, yref=None, act_kind=ACT_NONE, slope=0.0):
+    def forward(ctx, x, scale, yref=None, act_kind=ACT_NONE, slope=0.0, bits=None):
         x = _req(x, "input")
         N, C, H, W = x.shape
         y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        check(L.sempyr_pool2_down(x.data_ptr(), _p(yref), y.data_ptr(), N * C, H, W, scale, act_kind, slope, _stream()),
+        check(L.sempyr_pool2_down(x.data_ptr(), _p(yref), _p(bits), y.data_ptr(), N * C, H, W, scale, act_kind, slope, _stream()),
               "sempyr_pool2_down")
-        ctx.save_for_backward(yref)
+        ctx.save_for_backward(yref, bits)
         ctx.cfg = (scale, act_kind, slope)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (yref,) = ctx.saved_tensors
+        yref, bits = ctx.saved_tensors
         scale, act_kind, slope = ctx.cfg
-        return _apply(_Pool2Up, g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
+        return _apply(_Pool2Up, g.contiguous(), scale, yref, act_kind, slope, bits), None, None, None, None, None
 
 
-def _pool2_up_raw(x, scale, yref=None, act_kind=ACT_NONE, slope=0.0, partials=None):
-    """`partials` ([N*C, h*w/512] floats): also receive per-row partial sums of the result (see sempyr_pool2_up)."""
+def _pool2_up_raw(x, scale, yref=None, act_kind=ACT_NONE, slope=0.0, partials=None, bits=None):
+    """`partials` ([N*C, h*w/512] floats): also receive per-row partial sums of the result (see sempyr_pool2_up).
+    `bits`: the sign bits of the fused stem convolution, instead of yref."""
     N, C, h, w = x.shape
     y = torch.empty((N, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-    check(L.sempyr_pool2_up(x.data_ptr(), _p(yref), y.data_ptr(), N * C, h, w, scale, act_kind, slope, _p(partials),
+    check(L.sempyr_pool2_up(x.data_ptr(), _p(yref), _p(bits), y.data_ptr(), N * C, h, w, scale, act_kind, slope, _p(partials),
                             _stream()), "sempyr_pool2_up")
     return y
 
@@ -1175,17 +1263,17 @@ class _Pool2Up(Function):
     """y = scale * nearest_up2(x) * act'(yref); yref = None: plain nearest upsample."""
 
     @staticmethod
-    def forward(ctx, x, scale, yref=None, act_kind=ACT_NONE, slope=0.0):
-        y = _pool2_up_raw(_req(x, "input"), scale, yref, act_kind, slope)
-        ctx.save_for_backward(yref)
+    def forward(ctx, x, scale, yref=None, act_kind=ACT_NONE, slope=0.0, bits=None):
+        y = _pool2_up_raw(_req(x, "input"), scale, yref, act_kind, slope, bits=bits)
+        ctx.save_for_backward(yref, bits)
         ctx.cfg = (scale, act_kind, slope)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (yref,) = ctx.saved_tensors
+        yref, bits = ctx.saved_tensors
         scale, act_kind, slope = ctx.cfg
-        return _apply(_Pool2Down, g.contiguous(), scale, yref, act_kind, slope), None, None, None, None
+        return _apply(_Pool2Down, g.contiguous(), scale, yref, act_kind, slope, bits), None, None, None, None, None
 
 
 def avg_pool2(x):

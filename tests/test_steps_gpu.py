@@ -319,3 +319,42 @@ def test_prefetched_iterations_match_in_place(dev):
         assert torch.equal(d1[k], d0[k]), k
     for k in g0:
         assert torch.equal(g1[k], g0[k]), k
+
+
+def test_zero_mask_shortcut_is_exact(dev):
+    """The generator does not convolve feature taps whose mask the mask setters tagged all-zero (quirk Q2: every level at or
+    above the selected layer).  A critic step + a generator step with the shortcut on must leave exactly the parameters,
+    BatchNorm buffers and losses that convolving the zeros leaves."""
+    from semantic_pyramid_for_image_generation_amd import generator as gen_mod
+    tm, G, D, C, tr, images, feats, masks0, z, z2, alpha = _setup(dev, 'res', 'instance_norm', True, 91, B=2)
+    d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
+    crit = tm.L1Loss()
+    gstate = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    dstate = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    fd = [f.to(dev) for f in feats]
+    images_d = ((images - 0.5) / 0.5).to(dev)
+
+    def run(skip):
+        saved = gen_mod.ZERO_SKIP
+        gen_mod.ZERO_SKIP = skip
+        try:
+            G.load_state_dict(gstate); D.load_state_dict(dstate)
+            d_opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            g_opt = _Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+            random.seed(3)
+            masks = [f.clone() for f in fd]
+            tm.setMasksPart2(masks, dev, 2)                  # levels 2, 3, 4 blocked; level 1 passes with a window
+            assert [getattr(m, '_sempyr_all_zero', None) for m in masks] == [False, False, True, True, True, True]
+            d = tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, fd, masks, z=z.to(dev), alpha=alpha.to(dev))
+            g = tm.train_generator(G, D, g_loss_fn, g_opt, 2, fd, crit, 2, C, tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD),
+                                   crit, crit, masks, [2], z=z.to(dev), z2=z2.to(dev))
+            torch.cuda.synchronize()
+            losses = {k: float(v) for k, v in list(d.items()) + list(g.items())}
+            return losses, {k: v.detach().clone() for k, v in G.state_dict().items()}
+        finally:
+            gen_mod.ZERO_SKIP = saved
+    l1, s1 = run(True)
+    l0, s0 = run(False)
+    assert l1 == l0
+    for k in s0:
+        assert torch.equal(s1[k], s0[k]), k
