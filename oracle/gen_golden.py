@@ -252,6 +252,8 @@ def gen_steps():
         ref_tm.setMasksPart2(masks, torch.device('cpu'), L)
         normalizer = recipes.normalize_clf
         log = {}
+        before = {('G', k): v.detach().clone() for k, v in G.named_parameters()}
+        before.update({('D', k): v.detach().clone() for k, v in D.named_parameters()})
         torch.manual_seed(seed + 1)
         with Recorder() as rec:
             d1 = ref_tm.train_discriminator(G, D, d_loss_fn, d_opt, images_d, features, masks)
@@ -264,6 +266,13 @@ def gen_steps():
         for tag, dct in (('d1', d1), ('g1', g1), ('d2', d2)):
             for k, v in dct.items():
                 log[f'{tag}.{k}'] = float(v)
+        # strided samples of what the three optimizer steps did to every parameter tensor (after - before): a check of the
+        # update itself, which tensor norms cannot see (a step of lr = 2e-4 moves a norm by less than any usable tolerance)
+        for (which, k), v0 in before.items():
+            v1 = dict((G if which == 'G' else D).named_parameters())[k].detach()
+            d = (v1.double() - v0.double()).flatten()
+            step = max(1, d.numel() // 256)
+            store[f'{name}.delta.{which}.{k}'] = d[::step][:256].float().numpy()
         meta[name] = {'seed': seed, 'L': L, 'losses': log,
                       'n_randn': len(rec.randn), 'n_rand': len(rec.rand),
                       'G_param_checksum': param_checksum(G), 'D_param_checksum': param_checksum(D),

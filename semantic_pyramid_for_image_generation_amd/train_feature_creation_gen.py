@@ -9,8 +9,8 @@ from . import optim
 
 from . import ops, parallel
 from .featuresCreatorGen import Features1ToImage, FeaturesDiscriminator, LevelUpFeaturesGenerator
-from .train_model import (L1Loss, Normalize, _ensure_train, _frozen, get_wgan_losses_fn, gradient_penalty, load_classifier,
-                          print_gpu_details)
+from .train_model import (L1Loss, Normalize, _critic_losses_batched, _ensure_train, _frozen, _one, _samplewise,
+                          get_wgan_losses_fn, gradient_penalty, load_classifier, print_gpu_details)
 
 args = None
 
@@ -33,10 +33,10 @@ def train_generator(features_gen, discriminator, classifier, features_gen_optimi
         next_level_features_loss = next_level_features_criterion(created, features[features_to_train - 1])
         losses_dictionary = {'generator_loss': generator_loss, 'features_loss': features_loss,
                              'next_level_loss': next_level_features_loss}
-        total_loss = generator_loss + features_loss + 0.2 * next_level_features_loss
+        total_loss = ops.lincomb([generator_loss, features_loss, next_level_features_loss], [1.0, 1.0, 0.2])
         features_gen.zero_grad()
         with ops.async_param_grads():
-            total_loss.backward()
+            total_loss.backward(_one(created.device))
     parallel.sync_gradients(features_gen)
     features_gen_optimizer.step()
     return losses_dictionary
@@ -50,17 +50,21 @@ def train_discriminator(features_gen, discriminator, discriminator_loss_fn, disc
     with torch.no_grad():
         fake_features = features_gen(features[features_to_train])
     real = features[features_to_train - 1]
-    real_logit = discriminator(real)
-    fake_logit = discriminator(fake_features)
-    real_loss, fake_loss = discriminator_loss_fn(real_logit, fake_logit)
+    if _samplewise(discriminator):
+        # no layer mixes samples: one critic pass over both batches (see train_model.train_discriminator)
+        logits = discriminator(ops.concat_rows([real, fake_features]))
+        real_loss, fake_loss = _critic_losses_batched(discriminator_loss_fn, logits, real.shape[0], fake_features.shape[0])
+    else:
+        real_loss, fake_loss = discriminator_loss_fn(discriminator(real), discriminator(fake_features))
     gp = gradient_penalty(discriminator, real, fake_features, alpha)
-    discriminator_loss = (real_loss + fake_loss) + gp * args.gradient_penalty_weight
+    discriminator_loss = ops.lincomb([real_loss, fake_loss, gp], [1.0, 1.0, args.gradient_penalty_weight])
+    d_loss = ops.lincomb([real_loss.detach(), fake_loss.detach()])
     discriminator.zero_grad()
     with ops.async_param_grads():
-        discriminator_loss.backward()
+        discriminator_loss.backward(_one(real.device))
     parallel.sync_gradients(discriminator)
     discriminator_optimizer.step()
-    return {'d_loss': real_loss + fake_loss, 'gp': gp}
+    return {'d_loss': d_loss, 'gp': gp}
 
 
 def sample(f1_to_img, features_generator, features, features_level):

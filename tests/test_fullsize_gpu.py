@@ -29,6 +29,22 @@ CASES = [
     ("G.b3 ups @8", (16, 512, 8, 8, 256, 3, 1, 1, 1, False), None, False),
     ("D.b5 4x4 s2 @8", (16, 512, 8, 8, 512, 4, 2, 1, 0, True), None, False),
     ("D.b4 4x4 s2 batch 32", (32, 256, 16, 16, 512, 4, 2, 1, 0, True), None, False),
+    # gen-type 'default' (BASELINE config 4): every ConvTranspose2d(k4, s2, p1) is the input gradient of the Conv2d listed
+    # here (checked through the adjoint identity), the 1x1 -> 4x4 head is k4 s1 p0; the 'default' critic stem is 4x4 s2 + LeakyReLU
+    ("Gd.b3 convT 512->256 @8->16", (16, 256, 16, 16, 512, 4, 2, 1, 0, False), None, False),
+    ("Gd.b5 convT 128->64 @32->64", (16, 64, 64, 64, 128, 4, 2, 1, 0, False), None, False),
+    ("Gd.last convT 64->3 @128->256", (16, 3, 256, 256, 64, 4, 2, 1, 0, False), None, False),
+    ("G.b1 convT 128->512 @1->4", (16, 512, 4, 4, 128, 4, 1, 0, 0, False), None, False),
+    ("Dd.first 4x4 s2 lrelu", (16, 3, 256, 256, 64, 4, 2, 1, 0, True), 'lrelu', False),
+    ("D.last 4x4 512->1", (16, 512, 4, 4, 1, 4, 1, 0, 0, True), None, False),
+    # train_feature_creation_gen.py at its default batch 64 (BASELINE config 5): FeaturesDiscriminator('res', level 3) and
+    # LevelUpFeaturesGenerator(4)
+    ("FD.l3 3x3 256->256 b64", (64, 256, 16, 16, 256, 3, 1, 1, 0, True), None, False),
+    ("FD.l3 1x1 256->512 b64", (64, 256, 16, 16, 512, 1, 1, 0, 0, True), None, False),
+    ("FD 3x3 512->512 @8 b64", (64, 512, 8, 8, 512, 3, 1, 1, 0, True), None, False),
+    ("FD.last 4x4 512->1 @4 b64", (64, 512, 4, 4, 1, 4, 1, 0, 0, True), None, False),
+    ("LU4 3x3 512->512 ups b64", (64, 512, 8, 8, 512, 3, 1, 1, 1, False), None, False),
+    ("LU4 3x3 512->256 @16 b64", (64, 512, 16, 16, 256, 3, 1, 1, 0, False), None, False),
 ]
 
 

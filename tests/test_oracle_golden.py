@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import check_summary, load_json, load_npz
+from golden_util import check_deltas, check_summary, load_json, load_npz
 from oracle import masks as omasks
 from oracle import nets, recipes, steps
 from oracle.resnet18_cpu import ResNet18
@@ -161,6 +161,8 @@ def test_train_steps_oracle(case):
     ms, _ = omasks.masks_part2([tuple(f.shape) for f in features], info['L'], random.Random(seed))
     masks = [torch.from_numpy(m) for m in ms]
     tr = steps.Trainer(_sd(G), _sd(D), clf_sd, gen_type, norm, use_diversity=div)
+    g_before = {k: tr.g[k].detach().clone() for k in tr.g_params}
+    d_before = {k: tr.d[k].detach().clone() for k in tr.d_params}
     rn = [torch.from_numpy(store[f'{name}.randn{i}']) for i in range(info['n_randn'])]
     ra = [torch.from_numpy(store[f'{name}.rand{i}']) for i in range(info['n_rand'])]
     images_d = (images - 0.5) / 0.5
@@ -177,3 +179,10 @@ def test_train_steps_oracle(case):
         assert abs(float(tr.g[k].detach().double().norm()) - v) <= 1e-4 * max(1.0, v), k
     for k, v in info['D_norms'].items():
         assert abs(float(tr.d[k].detach().double().norm()) - v) <= 1e-4 * max(1.0, v), k
+    # the reference's parameter gradients of the last D / G step, and what the three optimizer steps did to every tensor
+    for k, v in info['D_grad_norms'].items():
+        assert abs(float(tr.d[k].grad.double().norm()) - v) <= 1e-3 * max(v, 1e-3 * max(info['D_grad_norms'].values())), ('D grad', k)
+    for k, v in info['G_grad_norms'].items():
+        assert abs(float(tr.g[k].grad.double().norm()) - v) <= 1e-3 * max(v, 1e-3 * max(info['G_grad_norms'].values())), ('G grad', k)
+    check_deltas(store, name, 'G', g_before, tr.g, info['G_grad_norms'], med_tol=0.01, frac_big=0.02)
+    check_deltas(store, name, 'D', d_before, tr.d, info['D_grad_norms'], med_tol=0.01, frac_big=0.02)

@@ -2,31 +2,35 @@
 
 Two kinds of check:
   * single step from the initial state vs the CPU oracle (itself pinned to the reference by
-    tests/test_oracle_golden.py) run in fp64: losses to 1e-3 relative and EVERY parameter gradient tensor to 3e-2 of
-    its max-abs — the check of backward and double backward.  Why 3e-2 and not 1e-3: at B=2 these gradients are
-    ill-conditioned in fp32 (sums of 1e5-1e6 cancelling products, LeakyReLU masks of pre-activations at round-off
-    distance from 0 entering twice through the penalty).  Measured against the fp64 oracle: the reference's own fp32
-    CPU path is 1.3e-3..1.9e-3 off with 8 threads; torch's OWN GPU kernels (every sempyr op swapped for
-    torch.nn.functional on the same GPU, tools/diag_bisect.py) are 1.6e-3 .. 1.9e-2 off — 1.9e-2 on
-    conv_block2's weight — and the HIP path measures the same 1.2e-3 .. 1.9e-2 on the same tensors, bit-identical
-    from run to run.  A formula error shows up as O(1), far outside that band.  On top of that, at most 0.5 % of a
-    tensor's elements (at least one) may be off by up to 0.2 of its max-abs: one LeakyReLU pre-activation at round-off
-    distance from 0 that lands on the other side flips act' between 1 and 0.2 for that element and moves exactly the
-    gradient entries it feeds (measured with the real+fake critic passes batched, which changes the split-K summation
-    order of conv_block5: 1 of 512 channels of its norm bias gradient moved by 7.1e-2 of scale, the other 511 agree to
-    1e-6; tools/diag_grads.py);
-  * the reference-generated 3-step trajectory (D, G, D with the reference's own z / alpha draws): losses before
-    the first update to 1e-3; later ones looser, because Adam's first update is lr*g/(|g|+eps) ~ lr*sign(g), which
-    turns round-off in structurally-zero gradients (conv biases in front of a norm layer) into +-lr steps: the
-    reference's own CPU code moves d2.gp by 0.5 % between 1 and 8 threads (measured), so 1e-3 is not attainable
-    by ANY implementation there."""
+    tests/test_oracle_golden.py) run in fp64: losses to 1e-3 relative and EVERY parameter gradient tensor against a bound
+    that is MEASURED in the test, not assumed: the same oracle is also run in fp32 (the reference's own arithmetic) four
+    times -- 1 thread, 8 threads, and twice with its floating-point inputs jittered by one unit in the last place -- and the
+    largest distance of those runs from fp64 is the noise of fp32 on this problem.  Per tensor,
+        max|g_hip - g_fp64| <= 3 * max(that tensor's distance, the median distance over the step's tensors,
+                                       the largest distance of any tensor of the step with its single worst element set aside),
+    relative to the tensor's max-abs: 1e-5 .. 1e-3 for most tensors, 1e-2 where the fp32 runs themselves disagree by that
+    much (a LeakyReLU pre-activation at round-off distance from zero lands on either side of it from run to run and
+    moves every gradient upstream of it -- which tensors are hit depends on where the flip happens, hence the last term).
+    Distances are taken with the same outlier allowance as the check itself (next sentence).  (At B=2 these gradients are ill-conditioned in fp32 -- sums of 1e5-1e6 cancelling
+    products -- and the fp32 CPU path itself is 1e-6 .. 3e-3 from fp64 depending on tensor and thread count;
+    tools/diag_grad_noise.py prints the table.)  On top of that, at most 0.5 % of a tensor's elements (at least one)
+    may be off by up to 0.2 of its max-abs: one LeakyReLU pre-activation at round-off distance from 0 that lands on the
+    other side flips act' between 1 and 0.2 for that element and moves exactly the gradient entries it feeds (1 of
+    512 channels of conv_block5's norm bias gradient moved by 7.1e-2 of scale, the other 511 agree to 1e-6).  A formula
+    error shows up as O(1) in whole tensors, far outside both;
+  * the reference-generated 3-step trajectory (D, G, D with the reference's own z / alpha draws): losses before the first
+    update to 1e-3; the reference's parameter-gradient norms; and what the three optimizer steps did to every parameter
+    (strided samples of after - before against the reference's, golden_util.check_deltas).  Later losses are looser,
+    because Adam's first update is lr*g/(|g|+eps) ~ lr*sign(g), which turns round-off in structurally-zero gradients
+    (conv biases in front of a norm layer) into +-lr steps: the reference's own CPU code moves d2.gp by 0.5 % between 1 and
+    8 threads (measured), so 1e-3 is not attainable by ANY implementation there."""
 import random
 from argparse import Namespace
 
 import pytest
 import torch
 
-from golden_util import cpu_state, load_json, load_npz
+from golden_util import check_deltas, cpu_state, load_json, load_npz
 from oracle import masks as omasks
 from oracle import nets, recipes
 
@@ -40,13 +44,38 @@ def _Adam(params, **kw):
 pytestmark = pytest.mark.gpu
 
 
-def _grad_close(name, got, want, global_max):
+def _rel_err(got, want, global_max):
     got = got.detach().cpu().double(); want = want.detach().cpu().double()
     scale = max(float(want.abs().max()), 1e-3 * global_max)
-    err = (got - want).abs()
-    outliers = int((err > 3e-2 * scale).sum())
-    assert outliers <= max(1, err.numel() // 200), (name, outliers, err.numel(), float(err.max()), scale)
-    assert float(err.max()) <= 0.2 * scale, (name, float(err.max()), scale)
+    return (got - want).abs() / scale
+
+
+def _grads_close(named_got, ref64, ref32_list, names):
+    """named_got: {name: HIP gradient}; ref64 / ref32_list: {name: tensor with .grad} of the fp64 oracle and of the fp32
+    oracle runs (different thread counts).  See the module docstring for the bound."""
+    gmax = max(float(ref64[k].grad.abs().max()) for k in names if ref64[k].grad is not None)
+
+    def robust_max(err):                 # the largest error once the allowed outliers (0.5 % of the elements, at least one) are set aside
+        flat = err.flatten()
+        drop = max(1, flat.numel() // 200)
+        return float(torch.topk(flat, min(drop + 1, flat.numel())).values[-1])
+    def second_max(err):
+        flat = err.flatten()
+        return float(torch.topk(flat, min(2, flat.numel())).values[-1])
+    live = [k for k in names if ref64[k].grad is not None]
+    noise = {k: max(robust_max(_rel_err(r[k].grad, ref64[k].grad, gmax)) for r in ref32_list) for k in live}
+    floor = sorted(noise.values())[len(noise) // 2]
+    top = max(second_max(_rel_err(r[k].grad, ref64[k].grad, gmax)) for r in ref32_list for k in live)
+    assert 1e-8 < floor < 1e-2 and top < 5e-2, (floor, top)     # the fp32 reference arithmetic itself: sanity of the measurement
+    for k in names:
+        if ref64[k].grad is None:
+            assert named_got[k] is None or float(named_got[k].abs().max()) == 0.0, k
+            continue
+        err = _rel_err(named_got[k], ref64[k].grad, gmax)
+        tol = 3.0 * max(noise[k], floor, top)
+        outliers = int((err > tol).sum())
+        assert outliers <= max(1, err.numel() // 200), (k, outliers, err.numel(), float(err.max()), tol, noise[k])
+        assert float(err.max()) <= 0.2, (k, float(err.max()))
 
 
 def _setup(dev, gen_type, norm, div, seed, B=2):
@@ -63,6 +92,7 @@ def _setup(dev, gen_type, norm, div, seed, B=2):
     # multi-threaded (measured: 8 threads 1.9e-3, 1 thread 4e-6 relative on D conv_block1 weight grads)
     f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     tr = steps.Trainer(f64(cpu_state(G)), f64(cpu_state(D)), f64(csd), gen_type, norm, use_diversity=div)
+    tr.fp32 = lambda: steps.Trainer(cpu_state(G), cpu_state(D), csd, gen_type, norm, use_diversity=div)
     C = Classifier(resnet18(365)); C.load_state_dict(csd)
     G.to(dev); D.to(dev); C.to(dev).eval()
     for p in C.parameters():
@@ -79,6 +109,49 @@ def _setup(dev, gen_type, norm, div, seed, B=2):
     return tm, G, D, C, tr, images, feats, masks, z, z2, alpha
 
 
+class _Jitter:
+    """`with _Jitter(seed):` -- tensors passed through j() are moved by about one unit in the last place"""
+    on = None
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __enter__(self):
+        _Jitter.on = self
+
+    def __exit__(self, *exc):
+        _Jitter.on = None
+
+
+def j(t):
+    """identity, or a one-ulp jitter of a float tensor (list) inside a _Jitter block"""
+    if _Jitter.on is None:
+        return t
+    if isinstance(t, (list, tuple)):
+        return [j(x) for x in t]
+    return t * (1.0 + 1.2e-7 * torch.randn(t.shape, generator=_Jitter.on.gen))
+
+
+def _fp32_runs(tr, step):
+    """The fp32 CPU oracle (= the reference's arithmetic) at two thread counts and twice with inputs jittered by an ulp
+    (`step` passes its tensors through j()): samples of how far fp32 itself lands from fp64 on this problem."""
+    out = []
+    saved = torch.get_num_threads()
+    try:
+        for nt, seed in ((1, None), (8, None), (8, 1), (8, 2)):
+            torch.set_num_threads(nt)
+            t = tr.fp32()
+            if seed is None:
+                step(t)
+            else:
+                with _Jitter(seed):
+                    step(t)
+            out.append(t)
+    finally:
+        torch.set_num_threads(saved)
+    return out
+
+
 def _d(ts):
     return [t.double() for t in ts] if isinstance(ts, (list, tuple)) else ts.double()
 
@@ -93,14 +166,13 @@ def test_d_step_gradients_vs_oracle(dev, case):
     tm, G, D, C, tr, images, feats, masks, z, z2, alpha = _setup(dev, gen_type, norm, div, 71)
     d_loss_fn, _ = tm.get_wgan_losses_fn()
     d_opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    refs32 = _fp32_runs(tr, lambda t: t.d_step(j((images - 0.5) / 0.5), j(feats), masks, j(z), alpha))
     want = tr.d_step(_d((images - 0.5) / 0.5), _d(feats), _d(masks), _d(z), _d(alpha))
     got = tm.train_discriminator(G, D, d_loss_fn, d_opt, ((images - 0.5) / 0.5).to(dev), [f.to(dev) for f in feats],
                                  [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
     for k in want:
-        assert abs(float(got[k]) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    gmax = max(float(tr.d[k].grad.abs().max()) for k in tr.d_params)
-    for k, p in D.named_parameters():
-        _grad_close(k, p.grad, tr.d[k].grad, gmax)
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _grads_close({k: p.grad for k, p in D.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params)
 
 
 @pytest.mark.parametrize("case", GRAD_CASES)
@@ -111,19 +183,15 @@ def test_g_step_gradients_vs_oracle(dev, case):
     _, g_loss_fn = tm.get_wgan_losses_fn()
     crit = tm.L1Loss()
     g_opt = _Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    refs32 = _fp32_runs(tr, lambda t: t.g_step(j(feats), masks, 3, j(z), j(z2) if div else None))
     want = tr.g_step(_d(feats), _d(masks), 3, _d(z), _d(z2) if div else None)
     got = tm.train_generator(G, D, g_loss_fn, g_opt, 2, [f.to(dev) for f in feats], crit, 3, C,
                              tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD), crit, crit, [m.to(dev) for m in masks], [2],
                              z=z.to(dev), z2=z2.to(dev) if div else None)
     assert set(got) == set(want)
     for k in want:
-        assert abs(float(got[k]) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    gmax = max(float(tr.g[k].grad.abs().max()) for k in tr.g_params if tr.g[k].grad is not None)
-    for k, p in G.named_parameters():
-        if tr.g[k].grad is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
-            continue
-        _grad_close(k, p.grad, tr.g[k].grad, gmax)
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _grads_close({k: p.grad for k, p in G.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params)
     assert all(p.requires_grad for p in D.parameters())         # the temporary freeze was undone
 
 
@@ -155,6 +223,8 @@ def test_train_steps(dev, case):
     crit = tm.L1Loss()
     g_opt = _Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     d_opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g_before = {k: v.detach().clone() for k, v in G.named_parameters()}
+    d_before = {k: v.detach().clone() for k, v in D.named_parameters()}
     images = recipes.image_batch(seed, 2).to(dev)
     normalizer_clf = tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD)
     normalizer_d = tm.Normalize([0.5, 0.5, 0.5], [0.5, 0.5, 0.5])
@@ -183,6 +253,17 @@ def test_train_steps(dev, case):
         assert abs(float(gsd[k].double().norm()) - v) <= 2e-3 * max(1.0, v), ('G', k)
     for k, v in info['D_norms'].items():
         assert abs(float(dsd[k].double().norm()) - v) <= 2e-3 * max(1.0, v), ('D', k)
+    # the reference's own gradient norms: G's are from g1 (behind one critic update), D's from d2 (behind a critic and a
+    # generator update), where trajectories have diverged at the percent level (module docstring): 10 %, a check against
+    # O(1) errors only -- the sharp gradient check is the single-step one above
+    for which, mod, key in (('G', G, 'G_grad_norms'), ('D', D, 'D_grad_norms')):
+        gmax = max(info[key].values())
+        grads = {k: p.grad for k, p in mod.named_parameters()}
+        for k, v in info[key].items():
+            assert abs(float(grads[k].double().norm()) - v) <= 0.1 * max(v, 1e-2 * gmax), (which, k, float(grads[k].double().norm()), v)
+    # ... and what the three optimizer steps did to every parameter tensor, against the reference's deltas
+    check_deltas(store, name, 'G', g_before, dict(G.named_parameters()), info['G_grad_norms'])
+    check_deltas(store, name, 'D', d_before, dict(D.named_parameters()), info['D_grad_norms'])
 
 
 def test_feature_gen_steps(dev):
@@ -358,3 +439,84 @@ def test_zero_mask_shortcut_is_exact(dev):
     assert l1 == l0
     for k in s0:
         assert torch.equal(s1[k], s0[k]), k
+
+
+FEATURE_GRAD_CASES = [(4, 'instance_norm'), (3, 'layer_norm'), (4, 'batch_norm')]
+
+
+@pytest.mark.parametrize("case", FEATURE_GRAD_CASES)
+def test_feature_gen_gradients_vs_oracle(dev, case):
+    """train_feature_creation_gen.py steps at gradient level: FeaturesDiscriminator('res') is built from the critic's
+    ResidualBlocks (skip + two 3x3 convs -> add -> LeakyReLU -> AvgPool2d, discriminator.py:49-71), whose double backward
+    only this path exercises; LevelUpFeaturesGenerator + the classifier stage behind it for the generator step.  Same
+    measured-noise bound as the image-level steps."""
+    from semantic_pyramid_for_image_generation_amd import train_feature_creation_gen as tf
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    from semantic_pyramid_for_image_generation_amd.classifier import Classifier, resnet18
+    from semantic_pyramid_for_image_generation_amd.featuresCreatorGen import FeaturesDiscriminator, LevelUpFeaturesGenerator
+    from oracle import steps
+    level, norm = case
+    seed = 83 + level
+    torch.manual_seed(seed)
+    FG = LevelUpFeaturesGenerator(level); FG.init_weights()
+    FD = FeaturesDiscriminator(norm, 'res', level - 1); FD.init_weights()
+    csd = {k: v.detach().clone() for k, v in recipes.make_resnet(seed).state_dict().items()}
+    f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    tr = steps.FeatureTrainer(f64(cpu_state(FG)), f64(cpu_state(FD)), f64(csd), level, norm, 'res')
+    tr.fp32 = lambda: steps.FeatureTrainer(cpu_state(FG), cpu_state(FD), csd, level, norm, 'res')
+    C = Classifier(resnet18(365)); C.load_state_dict(csd)
+    FG.to(dev); FD.to(dev); C.to(dev).eval()
+    for p in C.parameters():
+        p.requires_grad_(False)
+    tf.args = Namespace(gradient_penalty_weight=10.0)
+    d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
+    crit = tm.L1Loss()
+    images = recipes.image_batch(seed, 2)
+    with torch.no_grad():
+        _, feats = nets.classifier_forward(csd, recipes.normalize_clf(images))
+    alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(seed))
+    fdev = [f.to(dev) for f in feats]
+    # critic step (gradient penalty on feature tensors)
+    refs32 = _fp32_runs(tr, lambda t: t.d_step(j(feats), alpha))
+    want = tr.d_step(_d(feats), _d(alpha))
+    got = tf.train_discriminator(FG, FD, d_loss_fn, _Adam(FD.parameters(), lr=2e-4, betas=(0.5, 0.999)), fdev, level,
+                                 alpha=alpha.to(dev))
+    for k in want:
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _grads_close({k: p.grad for k, p in FD.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params)
+
+
+@pytest.mark.parametrize("case", FEATURE_GRAD_CASES[:2])
+def test_feature_gen_generator_gradients_vs_oracle(dev, case):
+    from semantic_pyramid_for_image_generation_amd import train_feature_creation_gen as tf
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    from semantic_pyramid_for_image_generation_amd.classifier import Classifier, resnet18
+    from semantic_pyramid_for_image_generation_amd.featuresCreatorGen import FeaturesDiscriminator, LevelUpFeaturesGenerator
+    from oracle import steps
+    level, norm = case
+    seed = 93 + level
+    torch.manual_seed(seed)
+    FG = LevelUpFeaturesGenerator(level); FG.init_weights()
+    FD = FeaturesDiscriminator(norm, 'res', level - 1); FD.init_weights()
+    csd = {k: v.detach().clone() for k, v in recipes.make_resnet(seed).state_dict().items()}
+    f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    tr = steps.FeatureTrainer(f64(cpu_state(FG)), f64(cpu_state(FD)), f64(csd), level, norm, 'res')
+    tr.fp32 = lambda: steps.FeatureTrainer(cpu_state(FG), cpu_state(FD), csd, level, norm, 'res')
+    C = Classifier(resnet18(365)); C.load_state_dict(csd)
+    FG.to(dev); FD.to(dev); C.to(dev).eval()
+    for p in C.parameters():
+        p.requires_grad_(False)
+    tf.args = Namespace(gradient_penalty_weight=10.0)
+    _, g_loss_fn = tm.get_wgan_losses_fn()
+    crit = tm.L1Loss()
+    images = recipes.image_batch(seed, 2)
+    with torch.no_grad():
+        _, feats = nets.classifier_forward(csd, recipes.normalize_clf(images))
+    refs32 = _fp32_runs(tr, lambda t: t.g_step(j(feats)))
+    want = tr.g_step(_d(feats))
+    got = tf.train_generator(FG, FD, C, _Adam(FG.parameters(), lr=2e-4, betas=(0.5, 0.999)), [f.to(dev) for f in feats], level,
+                             g_loss_fn, crit, crit)
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _grads_close({k: p.grad for k, p in FG.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params)
