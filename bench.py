@@ -118,8 +118,12 @@ def main():
     G, D, C = build_models(device, a.gen_type, a.discriminator_norm)
     parallel.broadcast_module(G); parallel.broadcast_module(D); parallel.broadcast_module(C)
     tm.args = Namespace(use_diversity_loss=a.use_diversity_loss, gradient_penalty_weight=10.0)
-    g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
-    d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
+    dp = {}
+    if world > 1:          # flat gradient buffers: one in-place RCCL all-reduce per optimizer step, 1/N folded into Adam
+        parallel.flatten_grads(G); parallel.flatten_grads(D)
+        dp = dict(grad_scale=1.0 / world, zero_grads=True)
+    g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True, **dp)
+    d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True, **dp)
     normalizer_clf = tm.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
 
     B = a.batch
@@ -129,7 +133,7 @@ def main():
     random.seed(0)                         # identical layer / crop draws on every rank
     # the loop body of train_model.py:300-349 (draws, classifier taps, masks, critic step, generator step every 5th
     # iteration) -- the object train_model._main drives; `--loop-mode` picks how the recorded body is issued
-    lp = loop.TrainLoop(G, D, C, g_opt, d_opt, B, device, use_graphs=(a.loop_mode != 'eager'),
+    lp = loop.TrainLoop(G, D, C, g_opt, d_opt, B, device, use_graphs=(a.loop_mode != 'eager' and world == 1),
                         executor='hip' if a.loop_mode == 'hipgraph' else 'own')
     it = [0]
 

@@ -3,10 +3,12 @@ for the CPU tests), identical parameters on every rank and ONE all-reduce of a f
 buffer per optimizer step.  The reference has no distributed code at all; this is
 the only collective on the path.  BatchNorm statistics and the diversity ratio stay per replica.
 
-The flat buffer is a persistent tensor per module (7.0 M floats for D, 9.5 M for G): gradients are
-packed with one multi-tensor copy, reduced with a single large collective (xGMI links are
-point-to-point, so one 28-38 MB ring/direct exchange beats ~100 small ones), scaled by 1/N and
-unpacked in place.
+The flat buffer is a persistent tensor per module (7.0 M floats for D, 9.5 M for G).  With
+`flatten_grads(module)` every `param.grad` IS a view of it: the weight-gradient kernels and the
+gradient-accumulation launch add into it in place, the collective runs on it directly (xGMI links are
+point-to-point, so one 28-38 MB exchange beats ~100 small ones), `optim.Adam(grad_scale=1/N,
+zero_grads=True)` reads the sum as a mean and leaves zeros behind for the next step -- no pack, no scale,
+no unpack pass.  Modules without flat gradients take the pack / reduce / scale / unpack route.
 """
 import os
 
@@ -111,10 +113,76 @@ def allreduce_mean_(tensors, group=None):
     torch._foreach_copy_(tensors, views)
 
 
+class FlatGrads:
+    """Persistent flat fp32 gradient buffer of a module; every `param.grad` is a view of it (see the module docstring)."""
+
+    def __init__(self, module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params or any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
+            raise ValueError("flatten_grads: contiguous fp32 parameters expected")
+        dev = params[0].device
+        # every view starts on a 16-byte boundary (float4 accesses of the Adam / accumulate kernels)
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.params, self.views = params, []
+        for p, off in zip(params, offs):
+            v = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = v
+            self.views.append(v)
+
+    def reattach(self):
+        """put the views back after something replaced `.grad` (zero_grad(set_to_none=True), a foreign optimizer)"""
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+
+def flatten_grads(module):
+    """Give `module` a persistent flat gradient buffer (idempotent).  The train steps then keep `.grad` instead of
+    resetting it to None (`zero_gradients`), and `sync_gradients` reduces the buffer in place; pair it with
+    optim.Adam(..., grad_scale=1 / world_size(), zero_grads=True)."""
+    fg = getattr(module, '_sempyr_flat_grads', None)
+    if fg is None:
+        fg = FlatGrads(module)
+        module._sempyr_flat_grads = fg
+    return fg
+
+
+def zero_gradients(module):
+    """`module.zero_grad()` of the train steps (train_model.py:115,141).  With flat gradients the buffer already holds
+    zeros at this point (written by the optimizer's last step, or by flatten_grads) and stays in place."""
+    fg = getattr(module, '_sempyr_flat_grads', None)
+    if fg is None:
+        module.zero_grad()
+    else:
+        fg.reattach()
+
+
+_REDUCER = None          # test hook: callable(flat tensor) standing for the all-reduce (sum) of a 1-process rehearsal
+
+
 def sync_gradients(module):
-    """Average `module`'s parameter gradients over the data-parallel ranks (no-op for a single process).
-    Called between backward and optimizer.step() by the train steps."""
+    """Sum (flat gradients: the optimizer divides) or average `module`'s parameter gradients over the data-parallel ranks;
+    no-op for a single process.  Called between backward and optimizer.step() by the train steps."""
+    fg = getattr(module, '_sempyr_flat_grads', None)
+    if _REDUCER is not None and fg is not None:
+        _REDUCER(fg.flat)
+        return
     if not is_distributed():
+        return
+    if fg is not None:
+        flat = fg.flat
+        if flat.is_cuda and _host_staged():
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            # RCCL runs the collective on its own stream behind everything queued on this one and orders this stream after
+            # it; the prefetch stream (next iteration's classifier taps + generator forward) keeps the GPU busy meanwhile
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return
     grads = []
     for p in module.parameters():

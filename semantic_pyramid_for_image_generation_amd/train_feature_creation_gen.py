@@ -34,7 +34,7 @@ def train_generator(features_gen, discriminator, classifier, features_gen_optimi
         losses_dictionary = {'generator_loss': generator_loss, 'features_loss': features_loss,
                              'next_level_loss': next_level_features_loss}
         total_loss = ops.lincomb([generator_loss, features_loss, next_level_features_loss], [1.0, 1.0, 0.2])
-        features_gen.zero_grad()
+        parallel.zero_gradients(features_gen)
         with ops.async_param_grads():
             total_loss.backward(_one(created.device))
     parallel.sync_gradients(features_gen)
@@ -59,7 +59,7 @@ def train_discriminator(features_gen, discriminator, discriminator_loss_fn, disc
     gp = gradient_penalty(discriminator, real, fake_features, alpha)
     discriminator_loss = ops.lincomb([real_loss, fake_loss, gp], [1.0, 1.0, args.gradient_penalty_weight])
     d_loss = ops.lincomb([real_loss.detach(), fake_loss.detach()])
-    discriminator.zero_grad()
+    parallel.zero_gradients(discriminator)
     with ops.async_param_grads():
         discriminator_loss.backward(_one(real.device))
     parallel.sync_gradients(discriminator)
@@ -119,8 +119,12 @@ def _main():
     criterion_discriminator, criterion_generator = get_wgan_losses_fn()
     next_level_features_criterion = L1Loss()
     criterion_features = L1Loss()
-    gen_optimizer = optim.Adam(features_generators[args.train_block_input - 2].parameters(), lr=args.lr, betas=(0.5, 0.999))
-    discriminator_optimizer = optim.Adam(discriminator.parameters(), lr=args.lr, betas=(0.5, 0.999))
+    dp = {}
+    if world > 1:
+        parallel.flatten_grads(features_generators[args.train_block_input - 2]); parallel.flatten_grads(discriminator)
+        dp = dict(grad_scale=1.0 / world, zero_grads=True)
+    gen_optimizer = optim.Adam(features_generators[args.train_block_input - 2].parameters(), lr=args.lr, betas=(0.5, 0.999), **dp)
+    discriminator_optimizer = optim.Adam(discriminator.parameters(), lr=args.lr, betas=(0.5, 0.999), **dp)
 
     starting_time = time.time()
     iterations = 0

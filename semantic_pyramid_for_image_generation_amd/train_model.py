@@ -253,7 +253,7 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
             loses_dictionary['diversity loss'] = diversity_loss
             loses_dictionary['total loss'] = total_loss
 
-        generator.zero_grad()
+        parallel.zero_gradients(generator)
         with ops.async_param_grads():
             total_loss.backward(_one(device))
     parallel.sync_gradients(generator)
@@ -446,7 +446,7 @@ def train_discriminator(generator, discriminator, discriminator_loss_fn, discrim
     discriminator_loss = ops.lincomb([real_images_d_loss, fake_images_d_loss, gp], [1.0, 1.0, args.gradient_penalty_weight])
     d_loss = ops.lincomb([real_images_d_loss.detach(), fake_images_d_loss.detach()])
 
-    discriminator.zero_grad()
+    parallel.zero_gradients(discriminator)
     with ops.async_param_grads():
         discriminator_loss.backward(_one(device))
     parallel.sync_gradients(discriminator)
@@ -617,14 +617,21 @@ def _main():
     parallel.broadcast_module(generator)
     parallel.broadcast_module(discriminator)
 
-    generator_optimizer = optim.Adam(generator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True)
-    discriminator_optimizer = optim.Adam(discriminator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True)
+    dp = {}
+    if world > 1:
+        # data parallel: .grad of every parameter is a view of one persistent flat buffer, summed in place by ONE RCCL
+        # all-reduce per optimizer step; Adam reads the sum as a mean (grad_scale) and leaves zeros behind (zero_grads)
+        parallel.flatten_grads(generator); parallel.flatten_grads(discriminator)
+        dp = dict(grad_scale=1.0 / world, zero_grads=True)
+    generator_optimizer = optim.Adam(generator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True, **dp)
+    discriminator_optimizer = optim.Adam(discriminator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True, **dp)
     from .loop import TrainLoop
     # the loop body (reference :300-349) lives in TrainLoop: same draws in the same order, the same step functions above,
     # replayed from captured graphs after the first occurrence of each variant
     loop = TrainLoop(generator, discriminator, classifier, generator_optimizer, discriminator_optimizer, args.batch_size, device,
                      discriminator_steps=args.discriminator_steps, train1_prob=args.train1_prob, fixed_layer=args.fixed_layer,
-                     normalizer_clf=normalizer_clf, normalizer_discriminator=normalizer_discriminator)
+                     normalizer_clf=normalizer_clf, normalizer_discriminator=normalizer_discriminator,
+                     use_graphs=False if world > 1 else None)       # (a collective inside a captured body is not rehearsed)
 
     starting_time = time.time()
     iterations = 0

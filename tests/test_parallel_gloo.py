@@ -60,3 +60,46 @@ def test_gradient_allreduce_world2():
     assert any(np.abs(a - b).max() > 1e-4 for a, b in zip(l0, l1))       # the ranks really had different grads
     for a, b in zip(p0, p1):
         assert np.array_equal(a, b)                                      # replicas stay bit-identical
+
+
+def _worker_flat(rank, world, port, q):
+    """the flat-gradient route: .grad are views of one persistent buffer, the collective sums it in place"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from semantic_pyramid_for_image_generation_amd import parallel
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    parallel.broadcast_module(net)
+    fg = parallel.flatten_grads(net)
+    assert parallel.flatten_grads(net) is fg and all(p.grad.data_ptr() % 16 == 0 for p in net.parameters())
+    out = []
+    for step in range(2):                            # second step: the views must still be the gradients
+        g = torch.Generator().manual_seed(10 + rank + 7 * step)
+        x = torch.randn(4, 6, generator=g)
+        parallel.zero_gradients(net)                 # keeps the views (the optimizer leaves zeros behind)
+        net[1](net[0](x)).pow(2).mean().backward()   # net[2] gets no gradient: its slice stays zero
+        local = fg.flat.clone()
+        parallel.sync_gradients(net)
+        out.append((local.numpy(), fg.flat.clone().numpy()))
+        assert all(p.grad is v for p, v in zip(fg.params, fg.views))
+        fg.flat.zero_()                              # what optim.Adam(zero_grads=True) does
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flat, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import numpy as np
+    for (l0, s0), (l1, s1) in zip(res[0][1], res[1][1]):
+        assert np.allclose(s0, l0 + l1, atol=1e-7) and np.array_equal(s0, s1)      # the SUM; Adam's grad_scale = 1/N makes it the mean
+        assert np.abs(l0 - l1).max() > 1e-4
