@@ -1,0 +1,152 @@
+"""Host-side compatibility pieces, no GPU needed: the classifier whole-module pickle shim
+(reference train_model.py:250, quirk Q8), the TensorBoard event writer, ImageFolder / loader / save_image."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import recipes
+
+
+def _reference_style_pickle(path, seed=4):
+    """What the reference saves: torch.save(Classifier(resnet18(...))) -- a pickle that names the classes
+    `classifier.Classifier` and `torchvision.models.resnet.{ResNet,BasicBlock}`.  Neither module exists here, so stand-ins
+    with those qualified names are registered while the file is written (and removed again before it is read)."""
+    from oracle.resnet18_cpu import ResNet18
+    src = recipes.make_resnet(seed)
+
+    tv = types.ModuleType('torchvision'); tvm = types.ModuleType('torchvision.models'); tvr = types.ModuleType('torchvision.models.resnet')
+    clf = types.ModuleType('classifier')
+
+    class BasicBlock(nn.Module):
+        pass
+
+    class ResNet(nn.Module):
+        pass
+
+    class Classifier(nn.Module):
+        pass
+    for cls, mod, name in ((BasicBlock, tvr, 'BasicBlock'), (ResNet, tvr, 'ResNet'), (Classifier, clf, 'Classifier')):
+        cls.__module__, cls.__qualname__, cls.__name__ = mod.__name__, name, name
+        setattr(mod, name, cls)
+
+    def clone_block(b):
+        nb = BasicBlock()
+        nb.conv1, nb.bn1, nb.relu, nb.conv2, nb.bn2, nb.downsample = b.conv1, b.bn1, b.relu, b.conv2, b.bn2, b.downsample
+        nb.stride = b.conv1.stride[0]
+        return nb
+    net = ResNet()
+    net.conv1, net.bn1, net.relu, net.maxpool = src.conv1, src.bn1, src.relu, src.maxpool
+    for i in range(1, 5):
+        setattr(net, 'layer%d' % i, nn.Sequential(*[clone_block(b) for b in getattr(src, 'layer%d' % i)]))
+    net.avgpool, net.fc = src.avgpool, src.fc
+    wrap = Classifier()                                   # classifier.py:16-30: the wrapper re-exposes the ResNet's children
+    for name in ('conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4', 'avgpool', 'fc'):
+        setattr(wrap, name, getattr(net, name))
+    wrap.flat = nn.Flatten()
+    names = {'torchvision': tv, 'torchvision.models': tvm, 'torchvision.models.resnet': tvr, 'classifier': clf}
+    saved = {k: sys.modules.get(k) for k in names}
+    sys.modules.update(names)
+    try:
+        torch.save(wrap, path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return src
+
+
+def test_load_classifier_whole_module_pickle(tmp_path):
+    from semantic_pyramid_for_image_generation_amd import compat
+    from semantic_pyramid_for_image_generation_amd.classifier import Classifier
+    from semantic_pyramid_for_image_generation_amd.resnet import HipStage
+    path = str(tmp_path / 'classifier18')
+    src = _reference_style_pickle(path)
+    assert 'classifier' not in sys.modules or not hasattr(sys.modules['classifier'], '__file__')
+    with pytest.raises(Exception):                        # the plain loader refuses the pickle (torch >= 2.6 default)
+        torch.load(path, weights_only=True)
+    model = compat.load_classifier(path)
+    assert isinstance(model, Classifier) and isinstance(model.layer3, HipStage)
+    want = src.state_dict()
+    got = model.state_dict()
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # a plain state_dict and the {'state_dict': {'module.*': ...}} layout of resnet18_places365.pth.tar (classifier.py:57-59)
+    p2 = str(tmp_path / 'sd.pt'); torch.save(want, p2)
+    p3 = str(tmp_path / 'sd.pth.tar'); torch.save({'state_dict': {'module.' + k: v for k, v in want.items()}}, p3)
+    for p in (p2, p3):
+        m = compat.load_classifier(p)
+        assert all(torch.equal(m.state_dict()[k], want[k]) for k in want)
+    with pytest.raises(TypeError):
+        bad = str(tmp_path / 'bad.pt'); torch.save([1, 2, 3], bad)
+        compat.load_classifier(bad)
+
+
+@pytest.mark.gpu
+def test_loaded_classifier_taps_equal_source(dev, tmp_path):
+    """the shim's model gives the taps of the network that was pickled"""
+    from semantic_pyramid_for_image_generation_amd import compat
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    from oracle import nets
+    path = str(tmp_path / 'classifier18')
+    src = _reference_style_pickle(path, seed=6)
+    model = compat.load_classifier(path, dev).eval()
+    x = recipes.image_batch(6, 2)
+    with torch.no_grad():
+        _, want = nets.classifier_forward({k: v.detach() for k, v in src.state_dict().items()}, recipes.normalize_clf(x))
+        _, got = model(tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD)(x.to(dev)))
+    for a, b in zip(got, want):
+        assert float((a.cpu() - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+
+
+def test_event_file_writer(tmp_path):
+    from semantic_pyramid_for_image_generation_amd import imageio
+    assert imageio.crc32c(b'123456789') == 0xE3069283                      # the CRC-32C check value
+    w = imageio.SummaryWriter(str(tmp_path / 'summaries'))
+    w.add_scalar('D/d_loss', -0.18185, global_step=1)
+    w.add_scalar('G/total loss', 99.8069, global_step=3)
+    w.add_scalar('D/gp', 12.5, global_step=2 ** 33)
+    w.close()
+    files = os.listdir(tmp_path / 'summaries')
+    assert len(files) == 1 and files[0].startswith('events.out.tfevents.')
+    got = imageio.read_event_scalars(str(tmp_path / 'summaries' / files[0]))
+    assert [(s, t) for s, t, _ in got] == [(1, 'D/d_loss'), (3, 'G/total loss'), (2 ** 33, 'D/gp')]
+    assert np.allclose([v for _, _, v in got], [-0.18185, 99.8069, 12.5], rtol=1e-6)
+    raw = open(tmp_path / 'summaries' / files[0], 'rb').read()
+    assert b'brain.Event:2' in raw[:64]                                     # the version record TensorBoard looks for
+
+
+def test_image_folder_loader_and_save(tmp_path):
+    from PIL import Image
+    from semantic_pyramid_for_image_generation_amd import imageio
+    rng = np.random.RandomState(0)
+    for cls, n, size in (('a', 3, (300, 280)), ('b', 2, (256, 512))):
+        os.makedirs(tmp_path / 'data' / cls)
+        for i in range(n):
+            Image.fromarray(rng.randint(0, 255, size + (3,), dtype=np.uint8)).save(tmp_path / 'data' / cls / f'{i}.png')
+    ds = imageio.ImageFolder(str(tmp_path / 'data'), image_size=256, crop_size=256)
+    assert len(ds) == 5 and ds.class_to_idx == {'a': 0, 'b': 1}
+    x, y = ds[4]
+    assert x.shape == (3, 256, 256) and x.dtype == torch.float32 and 0.0 <= float(x.min()) and float(x.max()) <= 1.0 and y == 1
+    # 256 x 512 (h x w): no resize, the centre 256 columns survive untouched (ToTensor = /255)
+    src = np.asarray(Image.open(tmp_path / 'data' / 'b' / '1.png'))
+    assert torch.equal(x, torch.from_numpy(src[:, 128:384]).permute(2, 0, 1).float().div(255))
+    loader = imageio.make_loader(ds, 2, shuffle=False, num_workers=0, drop_last=True)
+    batches = list(loader)
+    assert len(batches) == 2 and batches[0][0].shape == (2, 3, 256, 256)
+    sharded = imageio.make_loader(ds, 1, shuffle=True, num_workers=0, drop_last=True, rank=1, world_size=2)
+    assert hasattr(sharded.sampler, 'set_epoch') and len(list(sharded)) == 2
+    grid = imageio.make_grid(batches[0][0], nrow=8, padding=2, normalize=False)
+    imageio.save_image(grid, str(tmp_path / 'g.jpg'))
+    back = np.asarray(Image.open(tmp_path / 'g.jpg'))
+    assert back.shape == (260, 518, 3)
+    with pytest.raises(FileNotFoundError):
+        os.makedirs(tmp_path / 'empty')
+        imageio.ImageFolder(str(tmp_path / 'empty'))
