@@ -51,38 +51,73 @@ def build_models(device, gen_type, norm, seed=0):
     return G, D, C
 
 
+def _cpu_threads():
+    """Threads for the CPU baseline: torch's default on this host, i.e. all cores unless the box pins a share of them
+    (OMP_NUM_THREADS: the GPU box gives a one-GPU job 16 and asks jobs to stay within it)."""
+    return torch.get_num_threads()
+
+
 def cpu_baseline(batch, diversity):
-    """The oracle (CPU restatement, kind 'port') on the host cores: 1 D step + 1 G step at the bench batch size,
-    combined with the reference schedule (5 D + 1 G per cycle)."""
+    """The oracle (CPU restatement, kind 'port') on the host cores: 1 classifier pass + 1 D step + 1 G step at the bench
+    batch size after a small warm-up, combined with the reference schedule (5 D + 1 G per cycle)."""
     from oracle import masks as omasks
     from oracle import nets, recipes, steps
     from semantic_pyramid_for_image_generation_amd.discriminator import Discriminator
     from semantic_pyramid_for_image_generation_amd.generator import Generator
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
+    cores = _cpu_threads()
     torch.manual_seed(0)
     G = Generator('res'); G.init_weights()
     D = Discriminator('instance_norm', 'res'); D.init_weights()
     clf_sd = {k: v.detach() for k, v in recipes.make_resnet(0).state_dict().items()}
-    tr = steps.Trainer(G.state_dict(), D.state_dict(), clf_sd, 'res', 'instance_norm', use_diversity=diversity)
-    images = recipes.image_batch(0, batch)
-    t0 = time.time()
-    with torch.no_grad():
-        _, feats = nets.classifier_forward(clf_sd, recipes.normalize_clf(images))
-    t_clf = time.time() - t0
-    ms, _ = omasks.masks_part2([tuple(f.shape) for f in feats], 3, random.Random(0))
-    masks = [torch.from_numpy(m) for m in ms]
-    g = torch.Generator().manual_seed(1)
-    z = torch.randn(batch, 128, 1, 1, generator=g); z2 = torch.randn(batch, 128, 1, 1, generator=g)
-    alpha = torch.rand(batch, 1, 1, 1, generator=g)
-    images_d = (images - 0.5) / 0.5
-    t0 = time.time(); tr.d_step(images_d, feats, masks, z, alpha); t_d = time.time() - t0
-    t0 = time.time(); tr.g_step(feats, masks, 3, z, z2 if diversity else None); t_g = time.time() - t0
+
+    def one(bs, timed):
+        tr = steps.Trainer(G.state_dict(), D.state_dict(), clf_sd, 'res', 'instance_norm', use_diversity=diversity)
+        images = recipes.image_batch(0, bs)
+        t0 = time.time()
+        with torch.no_grad():
+            _, feats = nets.classifier_forward(clf_sd, recipes.normalize_clf(images))
+        t_clf = time.time() - t0
+        ms, _ = omasks.masks_part2([tuple(f.shape) for f in feats], 3, random.Random(0))
+        masks = [torch.from_numpy(m) for m in ms]
+        g = torch.Generator().manual_seed(1)
+        z = torch.randn(bs, 128, 1, 1, generator=g); z2 = torch.randn(bs, 128, 1, 1, generator=g)
+        alpha = torch.rand(bs, 1, 1, 1, generator=g)
+        images_d = (images - 0.5) / 0.5
+        t0 = time.time(); tr.d_step(images_d, feats, masks, z, alpha); t_d = time.time() - t0
+        t0 = time.time(); tr.g_step(feats, masks, 3, z, z2 if diversity else None); t_g = time.time() - t0
+        return t_clf, t_d, t_g
+    one(2, False)                                   # warm-up: thread pools, oneDNN primitive caches, allocator
+    t_clf, t_d, t_g = one(batch, True)
     cycle = 5 * (t_clf + t_d) + t_g
-    return {"value": 5.0 / cycle, "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU restatement) at batch {batch}: 1 classifier pass {t_clf:.2f}s + 1 D step {t_d:.2f}s "
-                      f"+ 1 G step {t_g:.2f}s, combined as 5*(clf+D)+G per cycle",
+    return {"value": 5.0 / cycle, "unit": "iters/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"oracle (torch-CPU restatement) at batch {batch}, after a batch-2 warm-up: 1 classifier pass {t_clf:.2f}s + "
+                      f"1 D step {t_d:.2f}s + 1 G step {t_g:.2f}s, combined as 5*(clf+D)+G per cycle",
             "torch": torch.__version__}
+
+
+def cpu_baseline_eval():
+    """eval_model.py loop on the host cores: 1 classifier pass + 2 eval-mode generator forwards at batch 8 after a warm-up
+    forward, extrapolated to the loop's 16 forwards per source batch (128 images)."""
+    from oracle import nets, recipes
+    from semantic_pyramid_for_image_generation_amd.generator import Generator
+    torch.manual_seed(0)
+    G = Generator('res'); G.init_weights()
+    gsd = {k: v.detach() for k, v in G.state_dict().items()}
+    clf_sd = {k: v.detach() for k, v in recipes.make_resnet(0).state_dict().items()}
+    images = recipes.image_batch(0, 8)
+    with torch.no_grad():
+        t0 = time.time(); _, feats = nets.classifier_forward(clf_sd, recipes.normalize_clf(images)); t_clf = time.time() - t0
+        masks = [torch.ones_like(f) for f in feats]
+        z = torch.randn(8, 128, 1, 1)
+        nets.generator_forward(gsd, 'res', z[:2], [f[:2] for f in feats], [m[:2] for m in masks], False)        # warm-up
+        t0 = time.time()
+        for _ in range(2):
+            nets.generator_forward(gsd, 'res', z, feats, masks, False)
+        t_g = (time.time() - t0) / 2
+    total = t_clf + 16 * t_g
+    return {"value": 128.0 / total, "unit": "images/s", "cores": _cpu_threads(), "os_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"oracle at batch 8: 1 classifier pass {t_clf:.2f}s + 2 generator forwards ({t_g:.2f}s each), "
+                      "extrapolated to 16 forwards = 128 images"}
 
 
 def main():
@@ -216,11 +251,19 @@ def main():
         eval_model.synthesize_batch(G, C, src, normalizer_clf)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        reps = 3
+        reps = 10
         for _ in range(reps):
             eval_model.synthesize_batch(G, C, src, normalizer_clf)
         torch.cuda.synchronize()
         eval_ips = reps * 128 / (time.perf_counter() - t1)
+        # kernel durations of the same loop for its roofline (second pass, HIP events around every conv launch)
+        ekms, ekl, ekf = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+        if timing:
+            _lib.check(_lib.lib.sempyr_profile_begin(4096), "sempyr_profile_begin")
+            for _ in range(2):
+                eval_model.synthesize_batch(G, C, src, normalizer_clf)
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(ekms), ctypes.byref(ekl), ctypes.byref(ekf)), "sempyr_profile_end")
         if world > 1:
             t = torch.tensor([eval_ips], dtype=torch.float64, device='cpu' if torch.distributed.get_backend() == 'gloo' else device)
             torch.distributed.all_reduce(t)
@@ -247,18 +290,31 @@ def main():
         }
         if eval_ips is not None:
             out["eval_images_per_sec"] = eval_ips
-            out["eval_config"] = "eval_model.py loop, gen-type res, batch 8, 4 levels x 4 noises, classifier pass included"
+            out["eval_config"] = "eval_model.py loop, gen-type res, batch 8, 4 levels x 4 noises, classifier pass included, 10 repetitions"
+            if timing and ekl.value > 0:
+                ach = ekf.value / (ekms.value * 1e-3) / 1e12
+                out["eval_roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launches": int(ekl.value),
+                                        "kernel_ms_total": ekms.value, "flops_counted_2MNK": ekf.value,
+                                        "note": "conv kernels of 2 repetitions of the loop, HIP events around every launch"}
+            if world == 1 and not a.no_cpu_baseline:
+                out["eval_cpu_baseline"] = cpu_baseline_eval()
         if timing and kl.value > 0:
-            achieved = cycle_flops * a.steps / (kms.value * 1e-3) / 1e12
-            # HBM-side bytes per launch of the same kernel: PMC passes cannot run inside this process, so the committed
-            # summary of tools/pmc_traffic.sh (same command line, see its "method" field) is quoted; None if absent.
-            traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_traffic.json")
+            # algorithmic FLOPs of the launches that ran (2*M*N*K on unpadded dims, summed by the library).  SURVEY 8(d)'s
+            # per-cycle figure is quoted beside it; it is ~4 % higher because convolutions of all-zero feature maps (masks of
+            # levels at or above the selected layer, quirk Q2) are not executed.
+            achieved = kf.value / (kms.value * 1e-3) / 1e12
+            # HBM-side bytes per launch: PMC passes cannot run inside this process; the committed per-kernel summary of the
+            # dominant family (tools/pmc_top3.sh -> profiles/r02_top3_traffic.json) is quoted; None if absent.
+            traffic = traffic_note = None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_top3_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("traffic_bytes_per_launch")
+                    top = json.load(f)["families"][0]
+                traffic = top["traffic_bytes_per_launch"]
+                traffic_note = f"{top['name']}: measured {traffic / 1e6:.0f} MB vs algorithmic {top['algorithmic_bytes'] / 1e6:.0f} MB per launch"
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                               "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_of": traffic_note,
                                "kernel": "implicit-GEMM conv kernels on fp32 v_mfma_f32_32x32x2_f32 (igemm_kernel fwd/dgrad/wgrad, patch3x3_kernel; incl. the VALU RGB-head launches)",
                                "launches": int(kl.value), "avg_launch_us": 1000.0 * kms.value / kl.value,
                                "kernel_ms_total": kms.value, "kernel_time_share": kms.value * 1e-3 / elapsed_instr,
@@ -267,8 +323,9 @@ def main():
                                        "steps, run single-stream so that each duration is the kernel's own (the headline "
                                        "pass overlaps branches and weight-gradient kernels on extra streams and records "
                                        "no events)",
-                               "flops_per_cycle_survey": cycle_flops, "flops_counted_2MNK": kf.value,
-                               "achieved_counted": kf.value / (kms.value * 1e-3) / 1e12}
+                               "flops_per_cycle_survey": cycle_flops, "flops_counted_2MNK_per_cycle": kf.value / a.steps,
+                               "achieved_on_survey_flops": cycle_flops * a.steps / (kms.value * 1e-3) / 1e12,
+                               "table": "profiles/r02_conv_family_table.csv (rocprofv3 kernel trace of the same single-stream pass)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, a.use_diversity_loss)
         print(json.dumps(out), flush=True)

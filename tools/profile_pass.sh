@@ -7,4 +7,4 @@ export SEMPYR_PROFILE_DUMP=$O/launches.csv
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O -o trace -- python3 $R/bench.py --profile-pass --steps $STEPS --no-cpu-baseline --no-eval > $O/log.txt 2>&1 || { echo "profile pass failed"; tail -5 $O/log.txt; exit 1; }
 tail -1 $O/log.txt
 T=$(find $O -name 'trace_kernel_trace.csv' | head -1)
-cd $R && python3 tools/roofline_table.py $T $O/launches.csv profiles/$TAG
+cd $R && python3 tools/roofline_table.py $T $O/launches.csv gpurun_out/$TAG && cp $O/log.txt gpurun_out/${TAG}_profile_pass_log.txt
