@@ -1780,6 +1780,9 @@ static int run_splitk_reduce(const float* slabs, float* out, const float* bias, 
     return 0;
 }
 
+int sempyr_stem_try_launch(const sempyr_conv_desc* d, const float* x, const float* w_packed, int Mpad, int Kpad, const float* bias,
+                           int act, float slope, float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits, void* stream);
+
 extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
                                  const int32_t* ktab, const float* bias, const float* scale, const float* res,
                                  int res_half, int act, float slope, float* y,
@@ -1824,6 +1827,10 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
         if (mask_bits && (act != SEMPYR_ACT_NONE || bias || act_bits)) SEMPYR_FAIL("conv fwd: mask bits replace bias / activation / sign-bit output");
         p.Bits = act_bits; p.MaskBits = mask_bits;
         if (mask_bits) p.slope = slope;
+        if (!y) {                       // pooled map (+ bits) only: the critic stem has a kernel of its own (stem.hip)
+            const int took = sempyr_stem_try_launch(d, x, wp, pl.Mpad, pl.Kpad[0], bias, act, slope, y_pooled, act_bits, mask_bits, stream);
+            if (took) return took == 1 ? 0 : took;
+        }
     }
     int rc = 0;
     if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) rc = launch_rgb3x3(p, st);
