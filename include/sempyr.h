@@ -125,6 +125,24 @@ int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, const float*
                         const int32_t* ktab_dgrad_dev, const float* bias, float* gx,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same input gradient for the critic stem (discriminator.py:101-109: Conv2d(3, 64, 3, 1, 1) -> LeakyReLU -> AvgPool2d(2)) from
+ * what its forward kept: gy = 0.25 * up2(g_pooled) * (bit ? 1 : slope) is expanded on the fly from the gradient of the POOLED
+ * output [B,Cout,Ho/2,Wo/2] and the sign bits sempyr_conv2d_fwd wrote (act_bits), so the full-resolution gradient never
+ * exists in memory (train_model.py:69-76, the inner pass of the gradient penalty; train_model.py:151-156 the generator's
+ * adversarial loss).  Needs the small-Cin 3x3 path (Cin <= 4, stride 1, pad 1) and Wo == 256. */
+int sempyr_conv2d_dgrad_unpooled(const sempyr_conv_desc* d, const float* g_pooled, const uint32_t* act_bits, float slope,
+                                 const float* wpacked_dgrad, const int32_t* ktab_dgrad_dev, float* gx, void* stream);
+
+/* Weight and bias gradient of that stem, also from (g_pooled, act_bits): gw[64,3,3,3] (+)= sum gy * x, gbias[64] (+)= sum gy
+ * with gy as above (gbias may be NULL).  Deterministic: per-workgroup partial sums in `workspace`
+ * (sempyr_stem_wgrad_workspace reports the bytes; it fails for other shapes than Cin 3, Cout 64, 3x3 s1 p1, Win % 256 == 0, Hin even),
+ * added in a fixed order.  Replaces un-pool + sempyr_conv2d_wgrad + sempyr_channel_sum for discriminator.py:105 in
+ * loss.backward() (train_model.py:139) and in the penalty's double backward. */
+int sempyr_stem_wgrad_workspace(const sempyr_conv_desc* d, size_t* bytes);
+int sempyr_stem_wgrad(const sempyr_conv_desc* d, const float* g_pooled, const uint32_t* act_bits, float slope,
+                      const float* x, float* gw, int accumulate_w, float* gbias, int accumulate_b,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* gw[Cout,Cin,kh,kw] = sum_{b,oy,ox} gy * x (deterministic split-K, fixed summation order); accumulate != 0: gw += that
  * sum (autograd's gradient accumulation for a weight used by several passes of one step — D(real), D(fake), D(x_hat) at
  * train_model.py:128-137 — folded into the combine pass instead of a separate add). */

@@ -71,6 +71,9 @@ SIGNATURES = {
     "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, _P, c_size_t, _P],
+    "sempyr_conv2d_dgrad_unpooled": [_DESC, _P, _P, c_float, _P, _P, _P, _P],
+    "sempyr_stem_wgrad_workspace": [_DESC, _P],
+    "sempyr_stem_wgrad": [_DESC, _P, _P, c_float, _P, _P, c_int, _P, c_int, _P, c_size_t, _P],
     "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P],
     "sempyr_norm_fwd": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, c_float, _P, _P, _P, _P],
     "sempyr_bn_eval_coeffs": [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P],

@@ -110,6 +110,9 @@ struct IgemmParams {
     // [b][m][OHW/32 words] -- all a ReLU-family backward needs of the full-resolution activation (1/32 of its bytes).
     // MaskBits (in): the accumulator is multiplied by act'(bit) before pooling (the double backward of that stem).
     uint32_t* Bits; const uint32_t* MaskBits;
+    // rgb3x3 kernel, FUSED: the gathered tensor is not in memory but 0.25 * up2(GP) * act'(GBits): GP is the gradient of the
+    // pooled stem output [B][C][GH/2][GW/2], GBits the stem's sign bits (quad order), gslope the LeakyReLU slope
+    const float* GP; const unsigned char* GBits; float gslope;
 };
 
 // UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
@@ -881,9 +884,10 @@ __global__ __launch_bounds__(256) void gather_small_m_kernel(const IgemmParams p
 // WAVE_ROW (image width == 256 = 64 lanes x 4 pixels): a wave is exactly one image row, so the pixel left / right of a
 // lane's quad is the neighbouring lane's (one DPP wave shift each, zero at the ends = the padding) and only the three
 // aligned float4 loads per channel remain.
-template <int NM, bool WAVE_ROW>
+template <int NM, bool WAVE_ROW, bool FUSED = false>
 __global__ __launch_bounds__(256) void rgb3x3_kernel(const IgemmParams p)
 {
+    static_assert(!FUSED || WAVE_ROW, "the fused un-pool path is built for 256-pixel rows");
     extern __shared__ float4 wl[];
     const int C = p.C;
     for (int k = threadIdx.x; k < 9 * C; k += 256) {
@@ -904,12 +908,19 @@ __global__ __launch_bounds__(256) void rgb3x3_kernel(const IgemmParams p)
     const int x0 = (r - y * W4) * 4;
     const float* xb = p.X + (size_t)b * p.XCHW;
     int ro[3]; bool rok[3];
+    int gro[3], gsh[3];                                        // FUSED: offset of the coarse pixel pair / bit shift of the row parity
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int yy = y + d - 1;
         rok[d] = (unsigned)yy < (unsigned)H;
-        ro[d] = (rok[d] ? yy : y) * W + x0;                    // out-of-image rows read row y and are zeroed below
+        const int yc = rok[d] ? yy : y;                        // out-of-image rows read row y and are zeroed below
+        ro[d] = yc * W + x0;
+        gro[d] = (yc >> 1) * (W >> 1) + (x0 >> 1);
+        gsh[d] = 2 * (yc & 1);
     }
+    const float* gpb = FUSED ? p.GP + (size_t)b * C * (p.XHW >> 2) : nullptr;
+    const unsigned char* gbb = FUSED ? p.GBits + (size_t)b * C * (p.XHW >> 3) : nullptr;
+    const float q1 = 0.25f, q0 = 0.25f * p.gslope;
     const bool lok = x0 > 0, rrok = x0 + 4 < W;
     const int xl = lok ? -1 : 0, xr = rrok ? 4 : 0;
     float acc[NM][4];
@@ -920,11 +931,24 @@ __global__ __launch_bounds__(256) void rgb3x3_kernel(const IgemmParams p)
 
     struct Stage { float4 c[3]; float l[3], r[3]; };
     auto load = [&](Stage& s, int ci) {
-        const float* pl = xb + (size_t)ci * p.XHW;
+        if constexpr (FUSED) {
+            // the lane's 4 pixels of row d are two pooling windows: one float2 of the pooled gradient + one byte of sign bits
+            const float* gl = gpb + (size_t)ci * (p.XHW >> 2);
+            const unsigned char* bl = gbb + (size_t)ci * (p.XHW >> 3);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            s.c[d] = *reinterpret_cast<const float4*>(pl + ro[d]);
-            if constexpr (!WAVE_ROW) { s.l[d] = pl[ro[d] + xl]; s.r[d] = pl[ro[d] + xr]; }
+            for (int d = 0; d < 3; ++d) {
+                const float2 g2 = *reinterpret_cast<const float2*>(gl + gro[d]);
+                const unsigned bt = (unsigned)bl[gro[d] >> 1] >> gsh[d];
+                s.c[d] = make_float4(g2.x * ((bt & 1u) ? q1 : q0), g2.x * ((bt & 2u) ? q1 : q0),
+                                     g2.y * ((bt & 16u) ? q1 : q0), g2.y * ((bt & 32u) ? q1 : q0));
+            }
+        } else {
+            const float* pl = xb + (size_t)ci * p.XHW;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                s.c[d] = *reinterpret_cast<const float4*>(pl + ro[d]);
+                if constexpr (!WAVE_ROW) { s.l[d] = pl[ro[d] + xl]; s.r[d] = pl[ro[d] + xr]; }
+            }
         }
     };
     auto compute = [&](const Stage& s, int ci) {
@@ -1465,6 +1489,7 @@ inline bool rgb3x3_ok(const sempyr_conv_desc* d, int mode) {
 
 int launch_rgb3x3(const IgemmParams& p, hipStream_t st) {
     if (((uintptr_t)p.X | (uintptr_t)p.Out) & 15) SEMPYR_FAIL("conv: rgb3x3 path needs 16-byte aligned tensors");
+    if (p.GP && (p.GW != 256 || ((uintptr_t)p.GP & 7))) SEMPYR_FAIL("conv: the fused un-pool input gradient needs 256-pixel rows");
     dim3 grid(ceil_div(p.N / 4, 256), 1, 1);
     const size_t lds = (size_t)9 * p.C * sizeof(float4);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1479,7 +1504,10 @@ int launch_rgb3x3(const IgemmParams& p, hipStream_t st) {
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
-    if (p.GW == 256) {
+    if (p.GP) {
+        if (p.M <= 3) hipLaunchKernelGGL((rgb3x3_kernel<3, true, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((rgb3x3_kernel<4, true, true>), grid, dim3(256), lds, st, p);
+    } else if (p.GW == 256) {
         if (p.M <= 3) hipLaunchKernelGGL((rgb3x3_kernel<3, true>), grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL((rgb3x3_kernel<4, true>), grid, dim3(256), lds, st, p);
     } else {
@@ -1847,13 +1875,16 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     return 0;
 }
 
-extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, const float* wp,
-                                   const int32_t* ktab, const float* bias, float* gx,
-                                   void* ws, size_t ws_bytes, void* stream)
+static int conv2d_dgrad_impl(const sempyr_conv_desc* d, const float* gy, const float* wp,
+                             const int32_t* ktab, const float* bias, float* gx,
+                             void* ws, size_t ws_bytes, void* stream,
+                             const float* g_pooled, const uint32_t* act_bits, float slope)
 {
     sempyr_conv_plan pl;
     if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_DGRAD, &pl)) return rc;
-    if (!gy || !wp || !ktab || !gx) SEMPYR_FAIL("conv dgrad: null pointer");
+    if ((!gy && !g_pooled) || !wp || !ktab || !gx) SEMPYR_FAIL("conv dgrad: null pointer");
+    if (g_pooled && (!act_bits || !rgb3x3_ok(d, SEMPYR_CONV_DGRAD) || pl.Wo != 256 || (pl.Ho & 1) || pl.splits[0] != 1))
+        SEMPYR_FAIL("conv dgrad: the un-pooled form is built for the critic stem (3x3 s1 p1, <= 4 input channels, 256-pixel rows)");
     if ((size_t)pl.workspace_bytes > ws_bytes || (pl.workspace_bytes && !ws))
         SEMPYR_FAIL("conv dgrad: workspace too small (%zu < %lld)", ws_bytes, (long long)pl.workspace_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -1880,6 +1911,7 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
     p.OSY = p.OSX = s;
     p.Out = target; p.bias = splits == 1 ? bias : nullptr; p.slab_stride = splits > 1 ? in_numel : 0;
     p.nphases = pl.nphases;
+    if (g_pooled) { p.GP = g_pooled; p.GBits = reinterpret_cast<const unsigned char*>(act_bits); p.gslope = slope; p.X = g_pooled; }
     int live = 0;
     for (int py = 0; py < s; ++py) for (int px = 0; px < s; ++px) {
         const int ph = py * s + px;
@@ -1914,6 +1946,19 @@ extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, c
     }
     if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, SEMPYR_ACT_NONE, 0.f, st);
     return 0;
+}
+
+extern "C" int sempyr_conv2d_dgrad(const sempyr_conv_desc* d, const float* gy, const float* wp,
+                                   const int32_t* ktab, const float* bias, float* gx,
+                                   void* ws, size_t ws_bytes, void* stream)
+{
+    return conv2d_dgrad_impl(d, gy, wp, ktab, bias, gx, ws, ws_bytes, stream, nullptr, nullptr, 0.f);
+}
+
+extern "C" int sempyr_conv2d_dgrad_unpooled(const sempyr_conv_desc* d, const float* g_pooled, const uint32_t* act_bits, float slope,
+                                            const float* wp, const int32_t* ktab, float* gx, void* stream)
+{
+    return conv2d_dgrad_impl(d, nullptr, wp, ktab, nullptr, gx, nullptr, 0, stream, g_pooled, act_bits, slope);
 }
 
 extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, const float* x,

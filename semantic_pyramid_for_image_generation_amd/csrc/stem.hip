@@ -182,6 +182,165 @@ __global__ __launch_bounds__(256, 3) void stem3x3_pool_kernel(const StemParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight (+ bias) gradient of the stem from what its forward kept: gW[m][c][ky][kx] = sum_{b,pix} gz[b][m][pix] * x[b][c][pix + tap],
+// gz = 0.25 * up2(gp) * act'(bits) built on the fly from the POOLED gradient gp and the sign bits -- the full-resolution
+// gradient (268 MB for 16 images) is neither written nor read.  One v_mfma_f32_32x32x2_f32 covers 32 channels (M) x 32 "taps"
+// (N: the 27 weights of a channel, column 27 = the bias gradient through a B-operand of ones) x 2 pixels (K); the reduction
+// runs over the pixels of the tile in quad order, so the two pixels of a k-step share one pooled value.  A workgroup walks
+// tiles t, t + grid, ..., keeps the 64 x 32 sums in registers, adds its four waves through LDS and writes one partial; a
+// second kernel adds the partials in a fixed order (deterministic).
+// MFMA bound: 2 MFMAs per pixel pair = 27 us per 16 images; HBM: 67 MB pooled gradient + 8.4 MB bits + 12.6 MB input.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int SW_CS = 4 * ST_PW + 4;         // channel stride of the patch: the 27 taps x 2 pixels of a B-fragment read hit distinct banks
+constexpr int SW_GP = 129;                   // pitch of the staged pooled-gradient tile [64][128]
+constexpr int SW_BP = 17;                    // pitch of the staged bit words [64][16]
+constexpr int SW_OUT = 64 * 32;              // sums per partial: [m][n], n = tap*3 + c (< 27), 27 = bias, 28..31 unused
+
+struct StemWgradParams {
+    const float* x;          // [B][3][H][W]
+    const float* gp;         // [B][64][H/2][W/2]
+    const uint32_t* bits;    // [B][64][H*W/32]
+    float* partials;         // [grid][SW_OUT]
+    int B, H, W, ntiles;
+    float slope;
+};
+
+__global__ __launch_bounds__(256, 3) void stem3x3_wgrad_kernel(const StemWgradParams p)
+{
+    __shared__ float patch[3 * SW_CS];
+    __shared__ float sgp[64 * SW_GP];                    // reused for the cross-wave reduction (4 x 2048 floats <= 64 x 129)
+    __shared__ uint32_t sb[64 * SW_BP];
+    static_assert(4 * SW_OUT <= 64 * SW_GP, "the reduction reuses the gradient tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ctiles = p.W / ST_COLS;
+    const int Wh = p.W >> 1, Hh = p.H >> 1;
+    const int wpp = (p.H * p.W) >> 5;
+    // B-operand: lane n = l31 reads the input at its tap; column 27 is the constant one, 28.. read tap 0 and are dropped
+    const int n_c = l31 % 3, n_tap = l31 / 3;
+    const int off = l31 < ST_K ? n_c * SW_CS + (n_tap / 3) * ST_PW + (n_tap % 3) : 0;
+    const bool ones = l31 == ST_K;
+    const float q1 = 0.25f, q0 = 0.25f * p.slope;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        int id = t;
+        const int ct = id % ctiles; id /= ctiles;
+        const int yp = id % Hh;
+        const int b = id / Hh;
+        const int x0 = ct * ST_COLS, y0 = 2 * yp;
+        const int win0 = yp * Wh + (x0 >> 1);
+        const float* xb = p.x + (size_t)b * 3 * p.H * p.W;
+        const float* gpt = p.gp + (size_t)b * 64 * Hh * Wh + win0;
+        const uint32_t* gbits = p.bits + (size_t)b * 64 * wpp + (win0 >> 3);
+        // global loads of the tile first, LDS stores after the barrier that ends the previous tile's reads
+        float v[12], v2 = 0.f;
+        {
+            const int gx = x0 - 1 + tid;
+            const bool in_x = gx >= 0 && gx < p.W;
+            const int gx2 = x0 + 255 + (tid & 1);
+            const bool in_x2 = gx2 < p.W;
+#pragma unroll
+            for (int rr = 0; rr < 12; ++rr) {
+                const int gy = y0 - 1 + (rr & 3);
+                const bool in_y = gy >= 0 && gy < p.H;
+                const float* row = xb + ((size_t)(rr >> 2) * p.H + (in_y ? gy : 0)) * p.W;
+                v[rr] = (in_y && in_x) ? row[gx] : 0.f;
+                if (tid >> 1 == rr) v2 = (in_y && in_x2) ? row[gx2] : 0.f;
+            }
+        }
+        float4 g4[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                    // element tid + 256 e: channel m = (tid >> 5) + 8 e, float4 column tid & 31
+            const int m = (tid >> 5) + 8 * e;
+            g4[e] = *reinterpret_cast<const float4*>(gpt + (size_t)m * Hh * Wh + 4 * (tid & 31));
+        }
+        uint32_t bw4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bw4[e] = gbits[(size_t)((tid >> 4) + 16 * e) * wpp + (tid & 15)];
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 12; ++rr) patch[(rr >> 2) * SW_CS + (rr & 3) * ST_PW + tid] = v[rr];
+        if (tid < 24) patch[(tid >> 3) * SW_CS + ((tid >> 1) & 3) * ST_PW + 256 + (tid & 1)] = v2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float* dst = &sgp[((tid >> 5) + 8 * e) * SW_GP + 4 * (tid & 31)];
+            dst[0] = g4[e].x; dst[1] = g4[e].y; dst[2] = g4[e].z; dst[3] = g4[e].w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sb[((tid >> 4) + 16 * e) * SW_BP + (tid & 15)] = bw4[e];
+        __syncthreads();
+
+        // wave w: windows 32 w .. 32 w + 31 of the tile = 4 word columns of 8 windows
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int wc = 4 * wave + j;
+            const uint32_t bw0 = sb[l31 * SW_BP + wc], bw1 = sb[(32 + l31) * SW_BP + wc];
+#pragma unroll
+            for (int win = 0; win < 8; ++win) {
+                const int wi = 8 * wc + win;                                  // window inside the tile
+                const float gp0 = sgp[l31 * SW_GP + wi], gp1 = sgp[(32 + l31) * SW_GP + wi];
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {                              // pixel pair (row pp, columns 2 wi, 2 wi + 1): k = half
+                    const int bit = 4 * win + 2 * pp + half;
+                    const float a0 = gp0 * (((bw0 >> bit) & 1u) ? q1 : q0);
+                    const float a1 = gp1 * (((bw1 >> bit) & 1u) ? q1 : q0);
+                    float bv = patch[pp * ST_PW + 2 * wi + half + off];
+                    bv = ones ? 1.f : bv;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- add the four waves (fixed order) and write this workgroup's partial ----
+    __syncthreads();
+    float* red = sgp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            red[wave * SW_OUT + (32 * i + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][r];
+    __syncthreads();
+    float* out = p.partials + (size_t)blockIdx.x * SW_OUT;
+#pragma unroll
+    for (int e = tid; e < SW_OUT; e += 256)
+        out[e] = (red[e] + red[SW_OUT + e]) + (red[2 * SW_OUT + e] + red[3 * SW_OUT + e]);
+}
+
+// out[o] (+)= sum_p partials[p][o]: 16 outputs per workgroup, 16 lanes per output walk the partials, fixed-order finish.
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partials, int nparts,
+                                                                float* __restrict__ gw, int acc_w, float* __restrict__ gb, int acc_b)
+{
+    __shared__ float red[16][17];
+    const int o16 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + o16;
+    float s = 0.f;
+    for (int q = pl; q < nparts; q += 16) s += partials[(size_t)q * SW_OUT + o];
+    red[pl][o16] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += red[q][o16];
+        const int m = o >> 5, n = o & 31;
+        if (n < ST_K) {
+            float* d = gw + m * ST_K + (n % 3) * 9 + n / 3;              // torch layout [m][c][ky][kx]
+            *d = acc_w ? *d + tot : tot;
+        } else if (n == ST_K && gb) {
+            gb[m] = acc_b ? gb[m] + tot : tot;
+        }
+    }
+}
+
+int stem_wgrad_grid(long long ntiles) { return (int)(ntiles < 768 ? ntiles : 768); }
+
 }  // namespace
 
 // Entry used by sempyr_conv2d_fwd (conv_igemm.hip) when the descriptor is the stem's: returns 1 when it took the launch,
@@ -206,4 +365,41 @@ int sempyr_stem_try_launch(const sempyr_conv_desc* d, const float* x, const floa
     else hipLaunchKernelGGL(stem3x3_pool_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     SEMPYR_CHECK_LAUNCH();
     return 1;
+}
+
+static bool stem_wgrad_shape_ok(const sempyr_conv_desc* d)
+{
+    return d->Cin == 3 && d->Cout == 64 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->ups == 0 &&
+           d->Win % ST_COLS == 0 && !(d->Hin & 1) && ((long long)d->Hin * d->Win) % 32 == 0;
+}
+
+extern "C" int sempyr_stem_wgrad_workspace(const sempyr_conv_desc* d, size_t* bytes)
+{
+    if (!d || !bytes) SEMPYR_FAIL("stem wgrad: null pointer");
+    if (!stem_wgrad_shape_ok(d)) SEMPYR_FAIL("stem wgrad: built for Conv2d(3 -> 64, 3x3, s1, p1) on rows that are a multiple of 256 pixels");
+    const long long ntiles = (long long)d->B * (d->Hin / 2) * (d->Win / ST_COLS);
+    *bytes = (size_t)stem_wgrad_grid(ntiles) * SW_OUT * sizeof(float);
+    return 0;
+}
+
+extern "C" int sempyr_stem_wgrad(const sempyr_conv_desc* d, const float* g_pooled, const uint32_t* act_bits, float slope,
+                                 const float* x, float* gw, int accumulate_w, float* gbias, int accumulate_b,
+                                 void* ws, size_t ws_bytes, void* stream)
+{
+    if (!d || !stem_wgrad_shape_ok(d)) SEMPYR_FAIL("stem wgrad: built for Conv2d(3 -> 64, 3x3, s1, p1) on rows that are a multiple of 256 pixels");
+    if (!g_pooled || !act_bits || !x || !gw || !ws) SEMPYR_FAIL("stem wgrad: null pointer");
+    if (((uintptr_t)g_pooled & 15)) SEMPYR_FAIL("stem wgrad: the pooled gradient must be 16-byte aligned");
+    const long long ntiles = (long long)d->B * (d->Hin / 2) * (d->Win / ST_COLS);
+    if (ntiles <= 0 || ntiles >= (1ll << 31)) SEMPYR_FAIL("stem wgrad: bad tile count");
+    const int grid = stem_wgrad_grid(ntiles);
+    if (ws_bytes < (size_t)grid * SW_OUT * sizeof(float)) SEMPYR_FAIL("stem wgrad: workspace too small (see sempyr_stem_wgrad_workspace)");
+    StemWgradParams p;
+    p.x = x; p.gp = g_pooled; p.bits = act_bits; p.partials = (float*)ws;
+    p.B = d->B; p.H = d->Hin; p.W = d->Win; p.ntiles = (int)ntiles; p.slope = slope;
+    hipLaunchKernelGGL(stem3x3_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    SEMPYR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(SW_OUT / 16), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, grid, gw, accumulate_w, gbias, accumulate_b);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
 }

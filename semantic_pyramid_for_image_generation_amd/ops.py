@@ -513,6 +513,71 @@ def _pooled_bits_ok(plan, act_kind):
             and plan.Ho % 2 == 0 and plan.Wo % 4 == 0 and plan.mode(CONV_FWD).info.splits[0] <= 1)
 
 
+_STEM_GRADS = os.environ.get("SEMPYR_STEM_GRADS", "1") != "0"
+
+
+def _stem_grads_ok(plan):
+    """The critic stem at a width its dedicated gradient kernels are built for (discriminator.py:105 on 256-pixel rows):
+    weight, bias and input gradients then come straight from (pooled gradient, sign bits)."""
+    return (_STEM_GRADS and plan.Cin == 3 and plan.Cout == 64 and plan.kh == 3 and plan.kw == 3 and plan.stride == 1
+            and plan.pad == 1 and not plan.ups and plan.Wo == 256 and plan.Ho % 2 == 0 and plan.mode(CONV_DGRAD).info.splits[0] <= 1)
+
+
+def _raw_stem_dgrad(plan, g, bits, slope, w):
+    """conv_transpose(0.25 * up2(g) * act'(bits), w) without the full-resolution intermediate (sempyr_conv2d_dgrad_unpooled)."""
+    mp = plan.mode(CONV_DGRAD)
+    wp = _packed_weights(plan, w, CONV_DGRAD)
+    gx = torch.empty((plan.B, plan.Cin, plan.Hin, plan.Win), dtype=torch.float32, device=g.device)
+    check(L.sempyr_conv2d_dgrad_unpooled(plan.desc_ref, g.data_ptr(), bits.data_ptr(), slope, wp.data_ptr(), mp.ktab.data_ptr(),
+                                         gx.data_ptr(), _stream()), "sempyr_conv2d_dgrad_unpooled")
+    return gx
+
+
+def _raw_stem_wgrad(plan, g, bits, slope, x, gw_into=None, want_b=False, gb_into=None):
+    """(gw, gb) of the stem from (pooled gradient, sign bits, input); `*_into`: existing gradients added to in place."""
+    nbytes = getattr(plan, "_stem_ws", None)
+    if nbytes is None:
+        out = ctypes.c_size_t(0)
+        check(L.sempyr_stem_wgrad_workspace(plan.desc_ref, ctypes.addressof(out)), "sempyr_stem_wgrad_workspace")
+        nbytes = plan._stem_ws = int(out.value)
+    ws = _workspace(nbytes, g.device)
+    gw = gw_into if gw_into is not None else torch.empty((plan.Cout, plan.Cin, plan.kh, plan.kw), dtype=torch.float32, device=g.device)
+    gb = None
+    if want_b:
+        gb = gb_into if gb_into is not None else torch.empty(plan.Cout, dtype=torch.float32, device=g.device)
+    check(L.sempyr_stem_wgrad(plan.desc_ref, g.data_ptr(), bits.data_ptr(), slope, x.data_ptr(), gw.data_ptr(),
+                              0 if gw_into is None else 1, _p(gb), 0 if gb_into is None else 1, _p(ws), nbytes, _stream()),
+          "sempyr_stem_wgrad")
+    return gw, gb
+
+
+def _stem_param_grads(g, bits, slope, x, plan, w, bias, want_b):
+    """Weight (+ bias) gradient of the stem; on the side stream straight into .grad when that is possible (returns None, None),
+    else returns the tensors."""
+    if not _can_async(w, bias, True, want_b):
+        return _raw_stem_wgrad(plan, g, bits, slope, x, want_b=want_b)
+    dev = g.device
+    main = _current_stream_obj(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    torch.cuda.set_stream(side)
+    try:
+        cur_w = _grad_in_place(w)
+        cur_b = _grad_in_place(bias) if want_b else None
+        gw, gb = _raw_stem_wgrad(plan, g, bits, slope, x, cur_w, want_b, cur_b)
+        if cur_w is None:
+            _accumulate_grad(w, gw, main)
+        if want_b and cur_b is None:
+            _accumulate_grad(bias, gb, main)
+    finally:
+        torch.cuda.set_stream(main)
+    g.record_stream(side)
+    x.record_stream(side)
+    bits.record_stream(side)
+    _SIDE_DIRTY.add(dev.index)
+    return None, None
+
+
 def _raw_conv_dgrad(plan, gy, w, bias):
     """plan.ups must be 0 here (callers pass plan.noups())."""
     mp = plan.mode(CONV_DGRAD)
@@ -593,6 +658,14 @@ class _ConvFwd(Function):
                 # input gradient only (gradient penalty's inner pass, generator step): one Function whose own backward
                 # (the penalty's double backward) is a single fused launch
                 return _apply(_StemInputGrad, gy, w, bits, plan, *ctx.act), None, None, None, None, None, None
+            if ctx.bits and want_w and not torch.is_grad_enabled() and _stem_grads_ok(plan) and gy.data_ptr() % 16 == 0:
+                # loss.backward() through the stem (train_model.py:139): every gradient straight from the pooled gradient
+                # and the sign bits, nothing full-resolution is materialised
+                slope = ctx.act[1] if ctx.act[0] == ACT_LRELU else 0.0
+                gy = _req(gy, "grad")
+                gw, gb = _stem_param_grads(gy, bits, slope, x, plan, w, bias, want_b)
+                gx = _raw_stem_dgrad(plan, gy, bits, slope, w) if ctx.needs_input_grad[0] else None
+                return gx, gw, gb, None, None, None, None
             if want_b and not torch.is_grad_enabled() and (h * wd) % 512 == 0 and wd % 2 == 0 and y.data_ptr() % 16 == 0:
                 # the un-pool pass also emits per-row partial sums: the bias gradient needs no second pass over the
                 # full-resolution gradient
@@ -625,9 +698,14 @@ class _StemInputGrad(Function):
     @staticmethod
     def forward(ctx, g, w, bits, plan, act_kind, slope):
         g = _req(g, "grad"); w = _req(w, "conv weight")
-        gz = _pool2_up_raw(g, 0.25, None, act_kind, slope, bits=bits)
-        gx = _raw_conv_dgrad(plan.noups(), gz, w, None)
-        ctx.save_for_backward(gz, w, bits)
+        ctx.direct = _stem_grads_ok(plan) and g.data_ptr() % 16 == 0
+        if ctx.direct:
+            gx = _raw_stem_dgrad(plan, g, bits, slope if act_kind == ACT_LRELU else 0.0, w)
+            ctx.save_for_backward(g, w, bits)
+        else:
+            gz = _pool2_up_raw(g, 0.25, None, act_kind, slope, bits=bits)
+            gx = _raw_conv_dgrad(plan.noups(), gz, w, None)
+            ctx.save_for_backward(gz, w, bits)
         ctx.plan = plan
         ctx.act = (act_kind, slope)
         return gx
@@ -642,7 +720,9 @@ class _StemInputGrad(Function):
         u = _req(u, "double-backward grad")
         g_g = g_w = None
         if not _INPUT_GRADS_ONLY and ctx.needs_input_grad[1]:
-            if _can_async(w, None, True, False):
+            if ctx.direct:          # `gz` is the pooled gradient here
+                g_w, _ = _stem_param_grads(gz, bits, slope if act_kind == ACT_LRELU else 0.0, u, plan, w, None, False)
+            elif _can_async(w, None, True, False):
                 _param_grads_async(gz, u, plan, w, None, True, False)
             else:
                 g_w = _raw_conv_wgrad(plan, gz, u)

@@ -173,6 +173,84 @@ def test_conv_double_backward(dev):
         assert rel_err(o, r) < 5e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 256), (1, 34, 256), (3, 2, 512)])
+@pytest.mark.parametrize("side", [False, True])
+def test_critic_stem_kernels(dev, shape, side):
+    """Conv2d(3, 64, 3, 1, 1) -> LeakyReLU(0.2) -> AvgPool2d(2) on 256-pixel rows (discriminator.py:105-109): the dedicated
+    forward kernel (pooled output + sign bits), the weight/bias-gradient kernel and the un-pooled input-gradient kernel that
+    work from (pooled gradient, bits), in a plain backward and in the penalty-style double backward; `side`: parameter
+    gradients on the side stream straight into .grad, twice (assign, then accumulate in place)."""
+    import contextlib
+    ops = _ops()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(5 + H)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g) * 0.1
+    gy = torch.randn(B, 64, H // 2, W // 2, generator=g)
+
+    def ref_f(x, w, b):
+        return F.avg_pool2d(F.leaky_relu(F.conv2d(x, w, b, 1, 1), 0.2), 2)
+
+    def hip_f(x, w, b):
+        return ops.conv2d(x, w, b, 1, 1, act_kind=ops.ACT_LRELU, slope=0.2, pool=True)
+
+    def plain(f, x, w, b, gy, reps, ctx=contextlib.nullcontext):
+        x = x.clone().requires_grad_(True); w = w.clone().requires_grad_(True); b = b.clone().requires_grad_(True)
+        with ctx():
+            for _ in range(reps):
+                y = f(x, w, b)
+                y.backward(gy)
+        return y, x.grad, w.grad, b.grad
+    reps = 2 if side else 1
+    ref = plain(ref_f, x, w, b, gy, reps)
+    out = plain(hip_f, x.to(dev), w.to(dev), b.to(dev), gy.to(dev), reps, ops.async_param_grads if side else contextlib.nullcontext)
+    torch.cuda.synchronize()
+    for name, o, r in zip(('y', 'gx', 'gw', 'gb'), out, ref):
+        assert rel_err(o, r) < 3e-5, (name, rel_err(o, r))
+
+    def penalty(f, x, w, b, inner=contextlib.nullcontext, ctx=contextlib.nullcontext):
+        x = x.clone().requires_grad_(True); w = w.clone().requires_grad_(True); b = b.clone().requires_grad_(True)
+        y = f(x, w, b)
+        pred = (y * y).sum() * 0.5
+        with inner():
+            gx, = torch.autograd.grad(pred, x, create_graph=True)
+        pen = (gx * gx).sum()
+        with ctx():
+            pen.backward()
+        return gx, x.grad, w.grad
+    ref = penalty(ref_f, x, w, b)
+    out = penalty(hip_f, x.to(dev), w.to(dev), b.to(dev), ops.input_grads_only, ops.async_param_grads if side else contextlib.nullcontext)
+    torch.cuda.synchronize()
+    for name, o, r in zip(('gx', 'ggx', 'ggw'), out, ref):
+        assert rel_err(o, r) < 1e-4, (name, rel_err(o, r))
+
+
+def test_stem_wgrad_entry_point(dev):
+    """sempyr_stem_wgrad on a shape the autograd route does not send it (two column tiles, more tiles than workgroups is
+    covered at full size): against the generic un-pool + weight-gradient + channel-sum kernels, with and without accumulate."""
+    ops = _ops()
+    B, H, W = 3, 4, 512
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 3, H, W, generator=g).to(dev)
+    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.2).to(dev)
+    b = (torch.randn(64, generator=g) * 0.1).to(dev)
+    gp = torch.randn(B, 64, H // 2, W // 2, generator=g).to(dev)
+    plan = ops.get_plan((B, 3, H, W, 64, 3, 3, 1, 1, 0), x.device)
+    bits = torch.empty(B * 64 * H * W // 32, dtype=torch.int32, device=dev)
+    pooled = torch.empty_like(gp)
+    ops._raw_conv_fwd(plan, x, w, b, ops.ACT_LRELU, 0.2, pooled, bits=bits, want_y=False)
+    gz = ops._pool2_up_raw(gp, 0.25, None, ops.ACT_LRELU, 0.2, bits=bits)
+    gw_ref = ops._raw_conv_wgrad(plan, gz, x)
+    gb_ref = gz.sum(dim=(0, 2, 3))
+    gw, gb = ops._raw_stem_wgrad(plan, gp, bits, 0.2, x, want_b=True)
+    assert rel_err(gw, gw_ref) < 2e-5 and rel_err(gb, gb_ref) < 2e-5
+    gw2, gb2 = ops._raw_stem_wgrad(plan, gp, bits, 0.2, x, gw.clone(), True, gb.clone())
+    assert torch.equal(gw2, gw + gw) and torch.equal(gb2, gb + gb)
+    gw3, none = ops._raw_stem_wgrad(plan, gp, bits, 0.2, x)
+    assert none is None and torch.equal(gw3, gw)
+
+
 NORM_KINDS = ['batch', 'instance', 'layer']
 
 
