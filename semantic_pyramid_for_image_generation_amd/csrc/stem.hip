@@ -61,24 +61,29 @@ __global__ __launch_bounds__(256, 3) void stem3x3_pool_kernel(const StemParams p
     uint32_t* gbits = p.bits + (size_t)b * 64 * wpp + (win0 >> 3);          // 16 consecutive words per channel
 
     // ---- stage the 3 x 4 x 258 input patch (zero outside the image) ----
+    // All loads are issued before the first use: out-of-image elements read a clamped address and are zeroed by the select
+    // at the LDS store (a load under a divergent branch is followed by a full vmcnt wait at the join, one round trip per row).
     const float* xb = p.x + (size_t)b * 3 * p.H * p.W;
     {
-        const int gx = x0 - 1 + tid;                              // patch column tid of every (channel, row); columns 256, 257 by the first threads
+        const int gx = x0 - 1 + tid;                              // patch column tid of every (channel, row)
         const bool in_x = gx >= 0 && gx < p.W;
-        const int gx2 = x0 + 255 + (tid & 1);                     // patch columns 256 / 257
-        const bool in_x2 = gx2 < p.W;
-        float v[12], v2 = 0.f;
+        const int gxc = min(max(gx, 0), p.W - 1);
+        float v[12];
 #pragma unroll
         for (int rr = 0; rr < 12; ++rr) {
             const int gy = y0 - 1 + (rr & 3);
-            const bool in_y = gy >= 0 && gy < p.H;
-            const float* row = xb + ((size_t)(rr >> 2) * p.H + (in_y ? gy : 0)) * p.W;
-            v[rr] = (in_y && in_x) ? row[gx] : 0.f;
-            if (tid >> 1 == rr) v2 = (in_y && in_x2) ? row[gx2] : 0.f;      // threads 2 rr, 2 rr + 1 fetch the two right halo columns of row rr
+            v[rr] = xb[((size_t)(rr >> 2) * p.H + min(max(gy, 0), p.H - 1)) * p.W + gxc];
         }
+        const int r2 = min(tid >> 1, 11);                         // threads 2 rr, 2 rr + 1 fetch patch columns 256 / 257 of row rr
+        const int gx2 = x0 + 255 + (tid & 1);
+        const int gy2 = y0 - 1 + (r2 & 3);
+        const float v2 = xb[((size_t)(r2 >> 2) * p.H + min(max(gy2, 0), p.H - 1)) * p.W + min(gx2, p.W - 1)];
 #pragma unroll
-        for (int rr = 0; rr < 12; ++rr) patch[rr * ST_PW + tid] = v[rr];
-        if (tid < 24) patch[(tid >> 1) * ST_PW + 256 + (tid & 1)] = v2;
+        for (int rr = 0; rr < 12; ++rr) {
+            const int gy = y0 - 1 + (rr & 3);
+            patch[rr * ST_PW + tid] = (in_x && gy >= 0 && gy < p.H) ? v[rr] : 0.f;
+        }
+        if (tid < 24) patch[r2 * ST_PW + 256 + (tid & 1)] = (gx2 < p.W && gy2 >= 0 && gy2 < p.H) ? v2 : 0.f;
     }
     if (MASKED) {
 #pragma unroll
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(256, 3) void stem3x3_pool_kernel(const StemParams p
 constexpr int SW_CS = 4 * ST_PW + 4;         // channel stride of the patch: the 27 taps x 2 pixels of a B-fragment read hit distinct banks
 constexpr int SW_GP = 129;                   // pitch of the staged pooled-gradient tile [64][128]
 constexpr int SW_BP = 17;                    // pitch of the staged bit words [64][16]
+constexpr int SW_ONES = ST_PW + 2 * 128 + 2;   // every (row pp, column) offset a B-operand read can have
 constexpr int SW_OUT = 64 * 32;              // sums per partial: [m][n], n = tap*3 + c (< 27), 27 = bias, 28..31 unused
 
 struct StemWgradParams {
@@ -206,9 +212,15 @@ struct StemWgradParams {
     float slope;
 };
 
-__global__ __launch_bounds__(256, 3) void stem3x3_wgrad_kernel(const StemWgradParams p)
+struct StemWgradTile {                       // one tile's global loads, held in registers while the previous tile is reduced
+    float v[12], v2;
+    float4 g4[8];
+    uint32_t bw4[4];
+};
+
+__global__ __launch_bounds__(256, 2) void stem3x3_wgrad_kernel(const StemWgradParams p)
 {
-    __shared__ float patch[3 * SW_CS];
+    __shared__ float patch[3 * SW_CS + SW_ONES];         // + a block of ones
     __shared__ float sgp[64 * SW_GP];                    // reused for the cross-wave reduction (4 x 2048 floats <= 64 x 129)
     __shared__ uint32_t sb[64 * SW_BP];
     static_assert(4 * SW_OUT <= 64 * SW_GP, "the reduction reuses the gradient tile");
@@ -219,17 +231,10 @@ __global__ __launch_bounds__(256, 3) void stem3x3_wgrad_kernel(const StemWgradPa
     const int wpp = (p.H * p.W) >> 5;
     // B-operand: lane n = l31 reads the input at its tap; column 27 is the constant one, 28.. read tap 0 and are dropped
     const int n_c = l31 % 3, n_tap = l31 / 3;
-    const int off = l31 < ST_K ? n_c * SW_CS + (n_tap / 3) * ST_PW + (n_tap % 3) : 0;
-    const bool ones = l31 == ST_K;
+    const int off = l31 < ST_K ? n_c * SW_CS + (n_tap / 3) * ST_PW + (n_tap % 3) : (l31 == ST_K ? 3 * SW_CS : 0);
     const float q1 = 0.25f, q0 = 0.25f * p.slope;
 
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    auto fetch = [&](StemWgradTile& T, int t) {
         int id = t;
         const int ct = id % ctiles; id /= ctiles;
         const int yp = id % Hh;
@@ -239,62 +244,98 @@ __global__ __launch_bounds__(256, 3) void stem3x3_wgrad_kernel(const StemWgradPa
         const float* xb = p.x + (size_t)b * 3 * p.H * p.W;
         const float* gpt = p.gp + (size_t)b * 64 * Hh * Wh + win0;
         const uint32_t* gbits = p.bits + (size_t)b * 64 * wpp + (win0 >> 3);
-        // global loads of the tile first, LDS stores after the barrier that ends the previous tile's reads
-        float v[12], v2 = 0.f;
-        {
-            const int gx = x0 - 1 + tid;
-            const bool in_x = gx >= 0 && gx < p.W;
-            const int gx2 = x0 + 255 + (tid & 1);
-            const bool in_x2 = gx2 < p.W;
+        // branch-free and select-free: out-of-image elements load a clamped address and are zeroed when the tile is written
+        // to LDS (a divergent load, or a select on the loaded value, would make the wave wait for memory right here)
+        const int gxc = min(max(x0 - 1 + tid, 0), p.W - 1);
 #pragma unroll
-            for (int rr = 0; rr < 12; ++rr) {
-                const int gy = y0 - 1 + (rr & 3);
-                const bool in_y = gy >= 0 && gy < p.H;
-                const float* row = xb + ((size_t)(rr >> 2) * p.H + (in_y ? gy : 0)) * p.W;
-                v[rr] = (in_y && in_x) ? row[gx] : 0.f;
-                if (tid >> 1 == rr) v2 = (in_y && in_x2) ? row[gx2] : 0.f;
-            }
+        for (int rr = 0; rr < 12; ++rr) {
+            const int gy = y0 - 1 + (rr & 3);
+            T.v[rr] = xb[((size_t)(rr >> 2) * p.H + min(max(gy, 0), p.H - 1)) * p.W + gxc];
         }
-        float4 g4[8];
+        {                                                // threads 2 rr, 2 rr + 1 fetch the two right halo columns of patch row rr
+            const int rr = min(tid >> 1, 11);
+            const int gx2 = x0 + 255 + (tid & 1);
+            const int gy = y0 - 1 + (rr & 3);
+            T.v2 = xb[((size_t)(rr >> 2) * p.H + min(max(gy, 0), p.H - 1)) * p.W + min(gx2, p.W - 1)];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {                    // element tid + 256 e: channel m = (tid >> 5) + 8 e, float4 column tid & 31
             const int m = (tid >> 5) + 8 * e;
-            g4[e] = *reinterpret_cast<const float4*>(gpt + (size_t)m * Hh * Wh + 4 * (tid & 31));
+            T.g4[e] = *reinterpret_cast<const float4*>(gpt + (size_t)m * Hh * Wh + 4 * (tid & 31));
         }
-        uint32_t bw4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bw4[e] = gbits[(size_t)((tid >> 4) + 16 * e) * wpp + (tid & 15)];
-        __syncthreads();
+        for (int e = 0; e < 4; ++e) T.bw4[e] = gbits[(size_t)((tid >> 4) + 16 * e) * wpp + (tid & 15)];
+    };
+
+    f32x16 acc[2];
 #pragma unroll
-        for (int rr = 0; rr < 12; ++rr) patch[(rr >> 2) * SW_CS + (rr & 3) * ST_PW + tid] = v[rr];
-        if (tid < 24) patch[(tid >> 3) * SW_CS + ((tid >> 1) & 3) * ST_PW + 256 + (tid & 1)] = v2;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    struct WgOperands { float gp[2][8]; float b[16]; uint32_t bw[2]; };
+    WgOperands ops[2];
+    auto lds_fetch = [&](WgOperands& O, int wc) {        // word column wc of the tile: windows 8 wc .. 8 wc + 7
+#pragma unroll
+        for (int i = 0; i < 2; ++i) O.bw[i] = sb[(32 * i + l31) * SW_BP + wc];
+#pragma unroll
+        for (int win = 0; win < 8; ++win) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) O.gp[i][win] = sgp[(32 * i + l31) * SW_GP + 8 * wc + win];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) O.b[2 * win + pp] = patch[pp * ST_PW + 2 * (8 * wc + win) + half + off];
+        }
+    };
+    for (int e = tid; e < SW_ONES; e += 256) patch[3 * SW_CS + e] = 1.f;       // what the bias column (lane 27) reads
+
+    StemWgradTile T;
+    if ((int)blockIdx.x < p.ntiles) fetch(T, blockIdx.x);
+    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();                                 // the previous tile's LDS reads are done
+        {
+            const int ct = t % ctiles, yp = (t / ctiles) % Hh;
+            const int x0 = ct * ST_COLS, y0 = 2 * yp;
+            const int gx = x0 - 1 + tid;
+            const bool in_x = gx >= 0 && gx < p.W;
+#pragma unroll
+            for (int rr = 0; rr < 12; ++rr) {
+                const int gy = y0 - 1 + (rr & 3);
+                patch[(rr >> 2) * SW_CS + (rr & 3) * ST_PW + tid] = (in_x && gy >= 0 && gy < p.H) ? T.v[rr] : 0.f;
+            }
+            if (tid < 24) {
+                const int gy = y0 - 1 + ((tid >> 1) & 3);
+                const bool ok = x0 + 255 + (tid & 1) < p.W && gy >= 0 && gy < p.H;
+                patch[(tid >> 3) * SW_CS + ((tid >> 1) & 3) * ST_PW + 256 + (tid & 1)] = ok ? T.v2 : 0.f;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float* dst = &sgp[((tid >> 5) + 8 * e) * SW_GP + 4 * (tid & 31)];
-            dst[0] = g4[e].x; dst[1] = g4[e].y; dst[2] = g4[e].z; dst[3] = g4[e].w;
+            dst[0] = T.g4[e].x; dst[1] = T.g4[e].y; dst[2] = T.g4[e].z; dst[3] = T.g4[e].w;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sb[((tid >> 4) + 16 * e) * SW_BP + (tid & 15)] = bw4[e];
+        for (int e = 0; e < 4; ++e) sb[((tid >> 4) + 16 * e) * SW_BP + (tid & 15)] = T.bw4[e];
         __syncthreads();
+        if (t + (int)gridDim.x < p.ntiles) fetch(T, t + gridDim.x);        // in flight while this tile is reduced
 
-        // wave w: windows 32 w .. 32 w + 31 of the tile = 4 word columns of 8 windows
-#pragma unroll 1
+        // wave w: windows 32 w .. 32 w + 31 of the tile = 4 word columns j of 8 windows.  The LDS operands of column j + 1
+        // are requested before the 32 MFMAs of column j are issued (the compiler otherwise sinks every ds_read to its use
+        // and the wave sits out the LDS latency once per k-step).
+        lds_fetch(ops[0], 4 * wave);
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int wc = 4 * wave + j;
-            const uint32_t bw0 = sb[l31 * SW_BP + wc], bw1 = sb[(32 + l31) * SW_BP + wc];
+            if (j < 3) lds_fetch(ops[(j + 1) & 1], 4 * wave + j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const WgOperands& O = ops[j & 1];
 #pragma unroll
             for (int win = 0; win < 8; ++win) {
-                const int wi = 8 * wc + win;                                  // window inside the tile
-                const float gp0 = sgp[l31 * SW_GP + wi], gp1 = sgp[(32 + l31) * SW_GP + wi];
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {                              // pixel pair (row pp, columns 2 wi, 2 wi + 1): k = half
                     const int bit = 4 * win + 2 * pp + half;
-                    const float a0 = gp0 * (((bw0 >> bit) & 1u) ? q1 : q0);
-                    const float a1 = gp1 * (((bw1 >> bit) & 1u) ? q1 : q0);
-                    float bv = patch[pp * ST_PW + 2 * wi + half + off];
-                    bv = ones ? 1.f : bv;
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+                    const float a0 = O.gp[0][win] * (((O.bw[0] >> bit) & 1u) ? q1 : q0);
+                    const float a1 = O.gp[1][win] * (((O.bw[1] >> bit) & 1u) ? q1 : q0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, O.b[2 * win + pp], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, O.b[2 * win + pp], acc[1], 0, 0, 0);
                 }
             }
         }
@@ -314,21 +355,29 @@ __global__ __launch_bounds__(256, 3) void stem3x3_wgrad_kernel(const StemWgradPa
         out[e] = (red[e] + red[SW_OUT + e]) + (red[2 * SW_OUT + e] + red[3 * SW_OUT + e]);
 }
 
-// out[o] (+)= sum_p partials[p][o]: 16 outputs per workgroup, 16 lanes per output walk the partials, fixed-order finish.
+// out[o] (+)= sum_p partials[p][o]: 16 outputs per workgroup, 16 lanes per output walk the partials (four independent
+// chains, so the loads overlap), fixed-order finish.
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partials, int nparts,
                                                                 float* __restrict__ gw, int acc_w, float* __restrict__ gb, int acc_b)
 {
     __shared__ float red[16][17];
     const int o16 = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int o = blockIdx.x * 16 + o16;
-    float s = 0.f;
-    for (int q = pl; q < nparts; q += 16) s += partials[(size_t)q * SW_OUT + o];
-    red[pl][o16] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int q = pl;
+    for (; q + 48 < nparts; q += 64) {
+        s0 += partials[(size_t)q * SW_OUT + o];
+        s1 += partials[(size_t)(q + 16) * SW_OUT + o];
+        s2 += partials[(size_t)(q + 32) * SW_OUT + o];
+        s3 += partials[(size_t)(q + 48) * SW_OUT + o];
+    }
+    for (; q < nparts; q += 16) s0 += partials[(size_t)q * SW_OUT + o];
+    red[pl][o16] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < 16) {
         float tot = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tot += red[q][o16];
+        for (int k = 0; k < 16; ++k) tot += red[k][o16];
         const int m = o >> 5, n = o & 31;
         if (n < ST_K) {
             float* d = gw + m * ST_K + (n % 3) * 9 + n / 3;              // torch layout [m][c][ky][kx]
@@ -339,7 +388,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
     }
 }
 
-int stem_wgrad_grid(long long ntiles) { return (int)(ntiles < 768 ? ntiles : 768); }
+int stem_wgrad_grid(long long ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }     // two resident workgroups per CU
 
 }  // namespace
 
