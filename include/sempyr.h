@@ -69,6 +69,8 @@ typedef struct sempyr_conv_plan {
     int64_t workspace_bytes;        /* split-K slabs */
     int32_t splits[SEMPYR_CONV_MAX_PHASES];
     int32_t cfg;                    /* tile configuration chosen */
+    int32_t stats_granule;          /* FWD: pixels per group of the BatchNorm-statistics epilogue (sempyr_conv2d_fwd_stats);
+                                       0 = this shape has none (split-K, RGB heads, shapes the 3x3 patch kernel does not take) */
 } sempyr_conv_plan;
 
 /* Shape inference + launch plan (host only, no GPU needed). */
@@ -117,6 +119,14 @@ int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp
                       int res_half, int act, float slope, float* y,
                       float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = conv2d(x, w) (no bias / activation: the convolution in front of a training-mode BatchNorm2d, generator.py:22-27) that
+ * also emits the BatchNorm statistics of y from its epilogue: tile_stats[(b*Cout + c) * G + g] = (sum, sum of squared
+ * deviations from the group mean) as float2 over pixels [g*granule, (g+1)*granule) of plane (b, c), G = Ho*Wo / granule,
+ * granule = sempyr_conv2d_plan().stats_granule (> 0 required).  sempyr_bn_stats_from_tiles turns them into the per-row
+ * coefficients; the separate statistics pass over y (one full read) is gone. */
+int sempyr_conv2d_fwd_stats(const sempyr_conv_desc* d, const float* x, const float* wpacked_fwd, const int32_t* ktab_fwd_dev,
+                            float* y, float* tile_stats, void* stream);
 
 /* gx[B,Cin,Hin<<ups,Win<<ups] = conv_transpose(gy, w) (+ bias[Cin] if bias != NULL: the bias of a
  * ConvTranspose2d whose forward this is). With ups=1 the result is the gradient in the upsampled
@@ -169,6 +179,15 @@ int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
                       const float* gamma, const float* beta,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                       int rep, float* rowbuf, float* scratch, void* stream);
+
+/* The statistics step of sempyr_norm_stats for SEMPYR_NORM_BATCH from the partial sums of sempyr_conv2d_fwd_stats instead of
+ * a pass over x: tile_stats[(n*C + c) * (HW/granule) + g] = float2 (sum, sum of squared deviations from the group mean).
+ * Writes the same rowbuf (mean, rstd, scale, shift per row) and running statistics (generator.py:23 BatchNorm2d in train
+ * mode; `rep` as in sempyr_norm_stats). */
+int sempyr_bn_stats_from_tiles(const float* tile_stats, int N, int C, int HW, int granule, float eps,
+                               const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                               int rep, float* rowbuf, void* stream);
 
 /* sempyr_norm_stats + the apply pass y = act((x - mean)*rstd*gamma + beta) as one call; InstanceNorm2d rows of up to 16384
  * elements (every critic layer, discriminator.py:16-26) run as ONE launch that reads x from HBM once. scratch: 2*N*C floats. */

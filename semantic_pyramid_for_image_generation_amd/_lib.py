@@ -31,7 +31,7 @@ class ConvPlanInfo(ctypes.Structure):
                 ("K", ctypes.c_int32 * MAX_PHASES), ("Kpad", ctypes.c_int32 * MAX_PHASES),
                 ("tab_off", ctypes.c_int32 * MAX_PHASES), ("tab_entries", ctypes.c_int32),
                 ("Mpad", ctypes.c_int32), ("wpack_floats", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64),
-                ("splits", ctypes.c_int32 * MAX_PHASES), ("cfg", ctypes.c_int32)]
+                ("splits", ctypes.c_int32 * MAX_PHASES), ("cfg", ctypes.c_int32), ("stats_granule", ctypes.c_int32)]
 
 
 class PackItem(ctypes.Structure):
@@ -69,12 +69,14 @@ SIGNATURES = {
     "sempyr_conv2d_pack_weights": [_DESC, c_int, _P, _P, _P, _P],
     "sempyr_conv2d_pack_weights_many": [ctypes.POINTER(PackItem), c_int, _P],
     "sempyr_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _P],
+    "sempyr_conv2d_fwd_stats": [_DESC, _P, _P, _P, _P, _P, _P],
     "sempyr_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P],
     "sempyr_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, _P, c_size_t, _P],
     "sempyr_conv2d_dgrad_unpooled": [_DESC, _P, _P, c_float, _P, _P, _P, _P],
     "sempyr_stem_wgrad_workspace": [_DESC, _P],
     "sempyr_stem_wgrad": [_DESC, _P, _P, c_float, _P, _P, c_int, _P, c_int, _P, c_size_t, _P],
     "sempyr_norm_stats": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P],
+    "sempyr_bn_stats_from_tiles": [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, _P, _P],
     "sempyr_norm_fwd": [c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, c_float, _P, _P, _P, _P],
     "sempyr_bn_eval_coeffs": [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P],
     "sempyr_norm_bwd": [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P],

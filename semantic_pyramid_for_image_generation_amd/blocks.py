@@ -28,9 +28,10 @@ def _single(v):
     return v[0] if isinstance(v, (tuple, list)) else v
 
 
-def run_conv(layer, x, upsample=False, act_kind=ops.ACT_NONE, slope=0.0, pool=False):
+def run_conv(layer, x, upsample=False, act_kind=ops.ACT_NONE, slope=0.0, pool=False, stats=False):
     """Execute an nn.Conv2d / nn.ConvTranspose2d container on the HIP implicit-GEMM path; an activation that
-    directly follows a Conv2d runs in the kernel epilogue."""
+    directly follows a Conv2d runs in the kernel epilogue.  `stats`: a training-mode BatchNorm2d consumes the result
+    (see ops.conv2d)."""
     stride, pad = _single(layer.stride), _single(layer.padding)
     if isinstance(layer, nn.ConvTranspose2d):
         if upsample:
@@ -38,7 +39,8 @@ def run_conv(layer, x, upsample=False, act_kind=ops.ACT_NONE, slope=0.0, pool=Fa
         y = ops.conv_transpose2d(x, layer.weight, layer.bias, stride, pad)
         y = ops.act(y, act_kind, slope) if act_kind != ops.ACT_NONE else y
         return ops.avg_pool2(y) if pool else y
-    return ops.conv2d(x, layer.weight, layer.bias, stride, pad, upsample=upsample, act_kind=act_kind, slope=slope, pool=pool)
+    return ops.conv2d(x, layer.weight, layer.bias, stride, pad, upsample=upsample, act_kind=act_kind, slope=slope, pool=pool,
+                      stats=stats)
 
 
 def run_norm(layer, x, act_kind=ops.ACT_NONE, slope=0.0, res=None):
@@ -90,7 +92,9 @@ def run_conv_norm(conv, norm, x, act_kind=ops.ACT_NONE, slope=0.0, res=None, ups
                                     act_kind=act_kind, slope=slope, res_half=res_half)
     if res_half:
         raise NotImplementedError("a half-resolution residual needs the fused conv + eval-BatchNorm path (see fuses_conv_norm)")
-    return run_norm(norm, run_conv(conv, x, upsample=upsample), act_kind, slope, res=res)
+    k = _train_norm_kind(norm)
+    return run_norm(norm, run_conv(conv, x, upsample=upsample, stats=k is not None and k[0] == ops.NORM_BATCH), act_kind, slope,
+                    res=res)
 
 
 def _train_norm_kind(layer):

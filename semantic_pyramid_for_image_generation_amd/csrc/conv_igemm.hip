@@ -113,6 +113,9 @@ struct IgemmParams {
     // rgb3x3 kernel, FUSED: the gathered tensor is not in memory but 0.25 * up2(GP) * act'(GBits): GP is the gradient of the
     // pooled stem output [B][C][GH/2][GW/2], GBits the stem's sign bits (quad order), gslope the LeakyReLU slope
     const float* GP; const unsigned char* GBits; float gslope;
+    // patch3x3 kernel, single pass: per (sample, channel) row and group of TN*32 consecutive pixels, (sum, sum of squared
+    // deviations from the group's mean) of the values written -- the BatchNorm statistics of the output without a pass over it
+    float2* Stats;
 };
 
 // UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
@@ -776,6 +779,39 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] = act_apply(acc[i][j][r16], p.act, p.slope);
+    }
+    if (p.Stats) {
+        // Two passes over the accumulators (sum, then squared deviations from the group's own mean: no cancellation), each
+        // closed by a 32-lane butterfly: quad permutes, the two row mirrors and a swizzle across the 16-lane rows.
+        constexpr int GR = TN * 32;
+        const int G = p.QHW / GR;
+        const int g = tr / GR + wn;                         // BN % GR == 0 and the tile starts at pixel tr of the plane
+        auto sum32 = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+            return v;
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                float sm = acc[i][0][r16];
+#pragma unroll
+                for (int j = 1; j < TN; ++j) sm += acc[i][j][r16];
+                sm = sum32(sm);
+                const float mu = sm * (1.f / GR);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { const float dv = acc[i][j][r16] - mu; q = fmaf(dv, dv, q); }
+                q = sum32(q);
+                const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                if (l31 == 0 && m < p.M) p.Stats[((size_t)tb * p.M + m) * G + g] = make_float2(sm, q);
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1569,10 +1605,10 @@ int launch_patch(const IgemmParams& p, int splits, hipStream_t st) {
     return 0;
 }
 
-// returns 1 if the launch was taken by the patch kernel, 0 if not eligible, < 0 / hipError on failure
-int try_patch(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int splits, hipStream_t st) {
+// The tile configuration the patch kernel would run this problem with, or -1 when it does not take it (fills p.PR/PW/CW).
+int patch_effective_cfg(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int splits) {
     static const int enabled = env_int("SEMPYR_PATCH", 1);
-    if (!enabled) return 0;
+    if (!enabled) return -1;
     if (cfg == CFG_64x256 && splits == 1) {                  // 64-row problems: narrower tiles when that evens out the rounds
         // 64x256 tiles run 3 per CU (768 at a time), 64x128 tiles 4 per CU (1024): take the shape whose last round is
         // fuller (N = 2^18: 1024 tiles = 1.33 rounds vs 2048 = 2.0 rounds; measured 0.204 -> 0.179 ms)
@@ -1583,8 +1619,18 @@ int try_patch(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int 
         if (force == 128 || (force == 0 && p.N % 256 == 0 && e128 > e256 + 0.15)) cfg = CFG_64x128;
     }
     int bm, bn; cfg_dims(cfg, bm, bn);
-    if (cfg != CFG_128x128 && cfg != CFG_64x256 && cfg != CFG_64x64 && cfg != CFG_64x128) return 0;
-    if (!patch3x3_ok(d, mode, bm, bn, p)) return 0;
+    if (cfg != CFG_128x128 && cfg != CFG_64x256 && cfg != CFG_64x64 && cfg != CFG_64x128) return -1;
+    if (!patch3x3_ok(d, mode, bm, bn, p)) return -1;
+    return cfg;
+}
+
+// pixels per statistics group of the patch kernel's BatchNorm-statistics epilogue (TN * 32 of the configuration)
+inline int patch_stats_granule(int cfg) { return cfg == CFG_64x64 ? 32 : 64; }
+
+// returns 1 if the launch was taken by the patch kernel, 0 if not eligible, < 0 / hipError on failure
+int try_patch(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int splits, hipStream_t st) {
+    cfg = patch_effective_cfg(d, mode, cfg, p, splits);
+    if (cfg < 0) return 0;
     int rc;
     if (cfg == CFG_128x128) rc = launch_patch<128, 128, 2, 2>(p, splits, st);
     else if (cfg == CFG_64x256) rc = launch_patch<64, 256, 1, 4>(p, splits, st);
@@ -1637,6 +1683,13 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn), plan->Kpad[0] / BK, plan->splits[0], cps);
         if (rgb3x3_ok(d, mode) && N >= 4096) plan->splits[0] = 1;
         plan->workspace_bytes = plan->splits[0] > 1 ? (long long)plan->splits[0] * out_numel * 4 : 0;
+        if (plan->splits[0] == 1 && !rgb3x3_ok(d, mode) && N < (1ll << 31)) {
+            // would the patch kernel take it?  (the geometry fields its eligibility test reads)
+            IgemmParams q{};
+            q.Mpad = plan->Mpad; q.N = (int)N; q.QHW = g.Ho * g.Wo; q.QW = g.Wo; q.ups = d->ups;
+            const int eff = patch_effective_cfg(d, mode, plan->cfg, q, 1);
+            if (eff >= 0 && (g.Ho * g.Wo) % patch_stats_granule(eff) == 0) plan->stats_granule = patch_stats_granule(eff);
+        }
     } else if (mode == SEMPYR_CONV_DGRAD) {
         const int s = d->stride;
         plan->nphases = s * s;
@@ -1811,10 +1864,11 @@ static int run_splitk_reduce(const float* slabs, float* out, const float* bias, 
 int sempyr_stem_try_launch(const sempyr_conv_desc* d, const float* x, const float* w_packed, int Mpad, int Kpad, const float* bias,
                            int act, float slope, float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits, void* stream);
 
-extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
-                                 const int32_t* ktab, const float* bias, const float* scale, const float* res,
-                                 int res_half, int act, float slope, float* y,
-                                 float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits, void* ws, size_t ws_bytes, void* stream)
+static int conv2d_fwd_impl(const sempyr_conv_desc* d, const float* x, const float* wp,
+                           const int32_t* ktab, const float* bias, const float* scale, const float* res,
+                           int res_half, int act, float slope, float* y,
+                           float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits, void* ws, size_t ws_bytes, void* stream,
+                           float* tile_stats)
 {
     sempyr_conv_plan pl;
     if (int rc = sempyr_conv2d_plan(d, SEMPYR_CONV_FWD, &pl)) return rc;
@@ -1861,9 +1915,14 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
         }
     }
     int rc = 0;
+    if (tile_stats) {
+        if (!pl.stats_granule || fused_pool || !y) SEMPYR_FAIL("conv fwd: this shape has no statistics epilogue (sempyr_conv2d_plan().stats_granule == 0)");
+        p.Stats = reinterpret_cast<float2*>(tile_stats);
+    }
     if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) rc = launch_rgb3x3(p, st);
     else {
         rc = fused_pool ? 0 : try_patch(d, SEMPYR_CONV_FWD, pl.cfg, p, splits, st);
+        if (rc == 0 && tile_stats) SEMPYR_FAIL("conv fwd: internal: the statistics epilogue was planned but the patch kernel declined");
         if (rc == 0) rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st);
         else if (rc == 1) rc = 0;
     }
@@ -1873,6 +1932,23 @@ extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, cons
     if (y_pooled && !fused_pool)
         return sempyr_pool2_down(y, nullptr, nullptr, y_pooled, d->B * d->Cout, pl.Ho, pl.Wo, 0.25f, SEMPYR_ACT_NONE, 0.f, stream);
     return 0;
+}
+
+extern "C" int sempyr_conv2d_fwd(const sempyr_conv_desc* d, const float* x, const float* wp,
+                                 const int32_t* ktab, const float* bias, const float* scale, const float* res,
+                                 int res_half, int act, float slope, float* y,
+                                 float* y_pooled, uint32_t* act_bits, const uint32_t* mask_bits, void* ws, size_t ws_bytes, void* stream)
+{
+    return conv2d_fwd_impl(d, x, wp, ktab, bias, scale, res, res_half, act, slope, y, y_pooled, act_bits, mask_bits, ws, ws_bytes,
+                           stream, nullptr);
+}
+
+extern "C" int sempyr_conv2d_fwd_stats(const sempyr_conv_desc* d, const float* x, const float* wp, const int32_t* ktab,
+                                       float* y, float* tile_stats, void* stream)
+{
+    if (!tile_stats) SEMPYR_FAIL("conv fwd stats: null statistics buffer");
+    return conv2d_fwd_impl(d, x, wp, ktab, nullptr, nullptr, nullptr, 0, SEMPYR_ACT_NONE, 0.f, y, nullptr, nullptr, nullptr,
+                           nullptr, 0, stream, tile_stats);
 }
 
 static int conv2d_dgrad_impl(const sempyr_conv_desc* d, const float* gy, const float* wp,

@@ -175,6 +175,55 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(int kind, const floa
     }
 }
 
+// BatchNorm statistics from the partial sums a convolution's epilogue left (sempyr_conv2d_fwd_stats): per (sample, channel)
+// row G groups of `granule` pixels, each (sum, sum of squared deviations from the group's mean).  One workgroup per
+// channel: mean of all N*G groups, then M2 = sum_g (M2_g + granule * (mean_g - mean)^2) (the pairwise-update formula, no
+// cancellation), then exactly the coefficient step of norm_finalize_kernel.  Fixed thread -> group map and a fixed reduction
+// tree: deterministic.
+__global__ __launch_bounds__(256) void bn_tile_finalize_kernel(const float2* __restrict__ tiles, int N, int C, int G, int granule,
+                                                               float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* running_mean, float* running_var, long long* nbt,
+                                                               float momentum, float rep,
+                                                               float* __restrict__ mean_row, float* __restrict__ rstd_row,
+                                                               float* __restrict__ scale_row, float* __restrict__ shift_row)
+{
+    __shared__ float sh[8];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int P = N * G;
+    const float inv_gr = 1.f / (float)granule;
+    float s[1] = {0.f};
+    for (int i = t; i < P; i += 256) {
+        const int b = i / G, g = i - b * G;
+        s[0] += tiles[((size_t)b * C + c) * G + g].x;
+    }
+    row_reduce<256, 1>(s, sh);
+    const float m = (float)P * (float)granule;
+    const float mean = s[0] / m;
+    __syncthreads();
+    float q[1] = {0.f};
+    for (int i = t; i < P; i += 256) {
+        const int b = i / G, g = i - b * G;
+        const float2 v = tiles[((size_t)b * C + c) * G + g];
+        const float d = v.x * inv_gr - mean;
+        q[0] += v.y + (float)granule * d * d;
+    }
+    row_reduce<256, 1>(q, sh);
+    const float m2 = q[0];
+    const float var = m2 / m;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = rstd * gamma[c], bt = beta[c];
+    for (int b = t; b < N; b += 256) {
+        const int row = b * C + c;
+        mean_row[row] = mean; rstd_row[row] = rstd; scale_row[row] = sc; shift_row[row] = bt;
+    }
+    if (t == 0 && running_mean) {
+        const float unbiased = m * rep > 1.f ? (m2 * rep) / (m * rep - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        if (c == 0 && nbt) *nbt += 1;
+    }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                       int N, int C, float* __restrict__ scale_row, float* __restrict__ shift_row)
@@ -837,6 +886,25 @@ extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW,
     const int ng = num_groups(kind, N, C);
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div((long long)ng * FIN_LPG, 256)), dim3(256), 0, st, kind, rmean, rm2, N, C, HW, eps,
                        gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, (float)rep,
+                       rowbuf, rowbuf + rows, rowbuf + 2 * rows, rowbuf + 3 * rows);
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sempyr_bn_stats_from_tiles(const float* tile_stats, int N, int C, int HW, int granule, float eps,
+                                          const float* gamma, const float* beta,
+                                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                          int rep, float* rowbuf, void* stream)
+{
+    if (int rc = check_norm_args(SEMPYR_NORM_BATCH, N, C, HW, 0)) return rc;
+    if (!tile_stats || !gamma || !beta || !rowbuf) SEMPYR_FAIL("bn_stats_from_tiles: null pointer");
+    if (granule < 1 || HW % granule != 0) SEMPYR_FAIL("bn_stats_from_tiles: %d pixels do not split into groups of %d", HW, granule);
+    if (rep < 1) SEMPYR_FAIL("bn_stats_from_tiles: replication factor %d", rep);
+    if (((uintptr_t)tile_stats & 7)) SEMPYR_FAIL("bn_stats_from_tiles: the statistics buffer must be 8-byte aligned");
+    const int rows = N * C;
+    hipLaunchKernelGGL(bn_tile_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(tile_stats), N, C, HW / granule, granule, eps, gamma, beta,
+                       running_mean, running_var, (long long*)num_batches_tracked, momentum, (float)rep,
                        rowbuf, rowbuf + rows, rowbuf + 2 * rows, rowbuf + 3 * rows);
     SEMPYR_CHECK_LAUNCH();
     return 0;

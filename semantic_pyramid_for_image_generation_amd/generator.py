@@ -64,7 +64,7 @@ class ResidualBlock(nn.Module):
             tail_takes_half_res(self.conv_block2.block[1], self.skip_block.block[1])
         residual = run_conv(self.skip_block.block[0], x, upsample=up and not half)
         h = self.conv_block1(x, upsample=up)
-        h = run_conv(self.conv_block2.block[0], h)
+        h = run_conv(self.conv_block2.block[0], h, stats=self.conv_block2.block[1].training)
         # BatchNorm(conv2) + BatchNorm(skip) -> add -> ReLU in one apply pass (both blocks have no activation of their own)
         return run_norm_add_norm_act(self.conv_block2.block[1], h, self.skip_block.block[1], residual, ops.ACT_RELU,
                                      b_half=half)

@@ -504,6 +504,31 @@ def _raw_conv_fwd(plan, x, w, bias, act_kind=ACT_NONE, slope=0.0, pooled=None, s
     return y
 
 
+_CONV_STATS = os.environ.get("SEMPYR_CONV_STATS", "1") != "0"
+_PENDING_STATS = []
+
+
+def conv_stats_granule(plan):
+    """Pixels per group of the BatchNorm-statistics epilogue of `plan`'s forward convolution; 0 = it has none."""
+    return int(plan.mode(CONV_FWD).info.stats_granule) if _CONV_STATS else 0
+
+
+def _raw_conv_fwd_stats(plan, x, w, granule):
+    """y = conv(x, w) and the per-group (sum, M2) partials of y for the BatchNorm that follows (sempyr_conv2d_fwd_stats)."""
+    mp = plan.mode(CONV_FWD)
+    wp = _packed_weights(plan, w, CONV_FWD)
+    y = torch.empty((plan.B, plan.Cout, plan.Ho, plan.Wo), dtype=torch.float32, device=x.device)
+    ts = torch.empty(2 * plan.B * plan.Cout * (plan.Ho * plan.Wo // granule), dtype=torch.float32, device=x.device)
+    check(L.sempyr_conv2d_fwd_stats(plan.desc_ref, x.data_ptr(), wp.data_ptr(), mp.ktab.data_ptr(), y.data_ptr(), ts.data_ptr(),
+                                    _stream()), "sempyr_conv2d_fwd_stats")
+    return y, ts
+
+
+def tile_stats_of(t):
+    """(partials, granule) a convolution's epilogue left for the BatchNorm statistics of `t`, or None."""
+    return getattr(t, "_sempyr_tile_stats", None)
+
+
 _STEM_BITS = os.environ.get("SEMPYR_STEM_BITS", "1") != "0"
 
 
@@ -622,12 +647,22 @@ class _ConvFwd(Function):
     (critic stem, discriminator.py:106-109)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, plan, act_kind=ACT_NONE, slope=0.0, pool=False):
+    def forward(ctx, x, w, bias, plan, act_kind=ACT_NONE, slope=0.0, pool=False, stats=0):
         x = _req(x, "conv input"); w = _req(w, "conv weight")
         if bias is not None:
             bias = _req(bias, "conv bias")
         if act_kind == ACT_TANH and pool:
             raise _lib.SempyrError("conv2d: pooled output needs a ReLU-family (or no) activation")
+        if stats:       # bias-free, no activation, no pool (checked by conv2d): the epilogue also leaves BatchNorm partials
+            y, ts = _raw_conv_fwd_stats(plan, x, w, stats)
+            _PENDING_STATS.append((ts, stats))
+            ctx.save_for_backward(x, w, None, None)
+            ctx.plan = plan
+            ctx.has_bias = False
+            ctx.act = (ACT_NONE, 0.0)
+            ctx.pool = False
+            ctx.bits = False
+            return y
         out = bits = None
         if pool:
             out = torch.empty((plan.B, plan.Cout, plan.Ho // 2, plan.Wo // 2), dtype=torch.float32, device=x.device)
@@ -657,7 +692,7 @@ class _ConvFwd(Function):
             if ctx.bits and ctx.needs_input_grad[0] and not (want_w or want_b):
                 # input gradient only (gradient penalty's inner pass, generator step): one Function whose own backward
                 # (the penalty's double backward) is a single fused launch
-                return _apply(_StemInputGrad, gy, w, bits, plan, *ctx.act), None, None, None, None, None, None
+                return _apply(_StemInputGrad, gy, w, bits, plan, *ctx.act), None, None, None, None, None, None, None
             if ctx.bits and want_w and not torch.is_grad_enabled() and _stem_grads_ok(plan) and gy.data_ptr() % 16 == 0:
                 # loss.backward() through the stem (train_model.py:139): every gradient straight from the pooled gradient
                 # and the sign bits, nothing full-resolution is materialised
@@ -665,7 +700,7 @@ class _ConvFwd(Function):
                 gy = _req(gy, "grad")
                 gw, gb = _stem_param_grads(gy, bits, slope, x, plan, w, bias, want_b)
                 gx = _raw_stem_dgrad(plan, gy, bits, slope, w) if ctx.needs_input_grad[0] else None
-                return gx, gw, gb, None, None, None, None
+                return gx, gw, gb, None, None, None, None, None
             if want_b and not torch.is_grad_enabled() and (h * wd) % 512 == 0 and wd % 2 == 0 and y.data_ptr() % 16 == 0:
                 # the un-pool pass also emits per-row partial sums: the bias gradient needs no second pass over the
                 # full-resolution gradient
@@ -686,7 +721,7 @@ class _ConvFwd(Function):
                     gb = _bias_grad(gy if bsrc is None else bsrc)
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(gy, w, plan)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class _StemInputGrad(Function):
@@ -797,11 +832,13 @@ class _ConvWgrad(Function):
         return g_gy, g_x, None
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NONE, slope=0.0, pool=False):
+def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NONE, slope=0.0, pool=False, stats=False):
     """nn.Conv2d forward (reference generator.py:25, discriminator.py:37), optionally reading its input
     through a fused nn.UpsamplingNearest2d(2) (generator.py:44,78) and applying a following activation
     (discriminator.py:106-107, generator.py:116-120) in the kernel epilogue.  `pool`: also apply the
-    nn.AvgPool2d(2) that follows (discriminator.py:109)."""
+    nn.AvgPool2d(2) that follows (discriminator.py:109).  `stats`: a training-mode BatchNorm2d follows (generator.py:23-27);
+    where the kernel has the epilogue for it, the result carries the statistics partials (tile_stats_of) and the norm skips
+    its pass over the tensor."""
     B, Cin, H, W = x.shape
     Cout, Cin_w, kh, kw = w.shape
     if Cin_w != Cin:
@@ -809,7 +846,13 @@ def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NO
     plan = get_plan((B, Cin, H, W, Cout, kh, kw, stride, padding, 1 if upsample else 0), x.device)
     if pool and (plan.Ho % 2 or plan.Wo % 2):
         raise _lib.SempyrError("conv2d: pooled output needs even output height and width")
-    return _apply(_ConvFwd, x, w, bias, plan, act_kind, slope, pool)
+    granule = conv_stats_granule(plan) if (stats and bias is None and act_kind == ACT_NONE and not pool) else 0
+    if not granule:
+        return _apply(_ConvFwd, x, w, bias, plan, act_kind, slope, pool)
+    del _PENDING_STATS[:]
+    y = _apply(_ConvFwd, x, w, bias, plan, act_kind, slope, pool, granule)
+    y._sempyr_tile_stats = _PENDING_STATS.pop()
+    return y
 
 
 class _ZeroConv(Function):
@@ -873,19 +916,28 @@ def _nchw(x):
     return N, C, x.numel() // (N * C)
 
 
-def _norm_stats(x, gamma, beta, kind, eps, bn_state, rep=1):
-    """per-row (mean, rstd, scale, shift) of a training-mode norm; updates the BatchNorm running statistics."""
+def _norm_stats(x, gamma, beta, kind, eps, bn_state, rep=1, tiles=None):
+    """per-row (mean, rstd, scale, shift) of a training-mode norm; updates the BatchNorm running statistics.
+    `tiles` = (partials, granule) from the producing convolution's epilogue (BATCH only): no pass over x."""
     N, C, HW = _nchw(x)
     rows = N * C
     rowbuf = torch.empty(4 * rows, dtype=torch.float32, device=x.device)
-    scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
     rm = rv = nbt = None
     momentum = 0.0
     if bn_state is not None:
         rm, rv, nbt, momentum = bn_state
-    check(L.sempyr_norm_stats(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(),
-                              _p(rm), _p(rv), _p(nbt), momentum, rep, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
-          "sempyr_norm_stats")
+    if tiles is not None and kind == NORM_BATCH:
+        ts, granule = tiles
+        if ts.numel() != 2 * rows * (HW // granule):
+            raise _lib.SempyrError("norm: the statistics partials do not belong to this tensor")
+        check(L.sempyr_bn_stats_from_tiles(ts.data_ptr(), N, C, HW, granule, eps, gamma.data_ptr(), beta.data_ptr(),
+                                           _p(rm), _p(rv), _p(nbt), momentum, rep, rowbuf.data_ptr(), _stream()),
+              "sempyr_bn_stats_from_tiles")
+    else:
+        scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
+        check(L.sempyr_norm_stats(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(),
+                                  _p(rm), _p(rv), _p(nbt), momentum, rep, rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
+              "sempyr_norm_stats")
     if bn_state is not None:      # the kernel updated the buffers through raw pointers: tell version-keyed caches
         torch.autograd.graph.increment_version(rm)
         torch.autograd.graph.increment_version(rv)
@@ -894,24 +946,30 @@ def _norm_stats(x, gamma, beta, kind, eps, bn_state, rep=1):
 
 class _NormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, kind, act_kind, slope, eps, bn_state):
+    def forward(ctx, x, gamma, beta, kind, act_kind, slope, eps, bn_state, tiles=None):
         x = _req(x, "norm input"); gamma = _req(gamma, "norm weight"); beta = _req(beta, "norm bias")
         N, C, HW = _nchw(x)
         rows = N * C
-        rowbuf = torch.empty(4 * rows, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
-        rm = rv = nbt = None
-        momentum = 0.0
-        if bn_state is not None:
-            rm, rv, nbt, momentum = bn_state
         y = torch.empty_like(x)
-        # statistics + apply in one call (one launch for InstanceNorm rows up to 16384 elements)
-        check(L.sempyr_norm_fwd(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(), _p(rm), _p(rv), _p(nbt),
-                                momentum, act_kind, slope, y.data_ptr(), rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
-              "sempyr_norm_fwd")
-        if bn_state is not None:      # the kernel updated the buffers through raw pointers: tell version-keyed caches
-            torch.autograd.graph.increment_version(rm)
-            torch.autograd.graph.increment_version(rv)
+        if tiles is not None and kind == NORM_BATCH:
+            # statistics from the producing convolution's epilogue, then the apply pass
+            rowbuf = _norm_stats(x, gamma, beta, kind, eps, bn_state, 1, tiles)
+            check(L.sempyr_affine_act(x.data_ptr(), rowbuf.data_ptr(), rowbuf.data_ptr() + 8 * rows, rowbuf.data_ptr() + 12 * rows, 0,
+                                      y.data_ptr(), rows, HW, act_kind, slope, _stream()), "sempyr_affine_act")
+        else:
+            rowbuf = torch.empty(4 * rows, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
+            rm = rv = nbt = None
+            momentum = 0.0
+            if bn_state is not None:
+                rm, rv, nbt, momentum = bn_state
+            # statistics + apply in one call (one launch for InstanceNorm rows up to 16384 elements)
+            check(L.sempyr_norm_fwd(kind, x.data_ptr(), N, C, HW, eps, gamma.data_ptr(), beta.data_ptr(), _p(rm), _p(rv), _p(nbt),
+                                    momentum, act_kind, slope, y.data_ptr(), rowbuf.data_ptr(), scratch.data_ptr(), _stream()),
+                  "sempyr_norm_fwd")
+            if bn_state is not None:      # the kernel updated the buffers through raw pointers: tell version-keyed caches
+                torch.autograd.graph.increment_version(rm)
+                torch.autograd.graph.increment_version(rv)
         ctx.save_for_backward(x, y if act_kind != ACT_NONE else None, gamma, rowbuf)
         ctx.cfg = (kind, act_kind, slope)
         ctx.beta_ref = _weak(beta)
@@ -929,7 +987,7 @@ class _NormAct(Function):
                 gg = None
             if _stash(ctx.beta_ref(), gb):
                 gb = None
-        return gx, gg, gb, None, None, None, None, None
+        return gx, gg, gb, None, None, None, None, None, None
 
 
 class _NormAddNormAct(Function):
@@ -938,7 +996,7 @@ class _NormAddNormAct(Function):
 
     @staticmethod
     def forward(ctx, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b,
-                b_half=False):
+                b_half=False, tiles_a=None):
         a = _req(a, "norm input"); b = _req(b, "norm input")
         if b_half:
             # b is the branch BEFORE a nearest x2 upsample (its 1x1 convolution commutes with the upsample): statistics on
@@ -951,7 +1009,7 @@ class _NormAddNormAct(Function):
         gamma_b = _req(gamma_b, "norm weight"); beta_b = _req(beta_b, "norm bias")
         N, C, HW = _nchw(a)
         rows = N * C
-        ra = _norm_stats(a, gamma_a, beta_a, kind, eps_a, state_a)
+        ra = _norm_stats(a, gamma_a, beta_a, kind, eps_a, state_a, 1, tiles_a)
         rb = _norm_stats(b, gamma_b, beta_b, kind, eps_b, state_b, 4 if b_half else 1)
         y = torch.empty_like(a)
         check(L.sempyr_affine2_act(a.data_ptr(), ra.data_ptr(), ra.data_ptr() + 8 * rows, ra.data_ptr() + 12 * rows,
@@ -986,7 +1044,7 @@ class _NormAddNormAct(Function):
                 ggb = None
             if _stash(beta_b, gbb):
                 gbb = None
-        return ga, gga, gba, None, gb, ggb, gbb, None, None, None, None, None, None, None
+        return ga, gga, gba, None, gb, ggb, gbb, None, None, None, None, None, None, None, None
 
 
 class _NormActBwd(Function):
@@ -1044,7 +1102,7 @@ def norm_act(x, gamma, beta, kind, act_kind=ACT_NONE, slope=0.0, eps=1e-5, bn_st
     """Training-mode BatchNorm2d / InstanceNorm2d(affine) / GroupNorm(1,C) fused with ReLU or
     LeakyReLU (reference generator.py:27-29, discriminator.py:37-39).  `bn_state` =
     (running_mean, running_var, num_batches_tracked, momentum) is updated in place for BATCH."""
-    return _apply(_NormAct, x, gamma, beta, kind, act_kind, slope, eps, bn_state)
+    return _apply(_NormAct, x, gamma, beta, kind, act_kind, slope, eps, bn_state, tile_stats_of(x) if kind == NORM_BATCH else None)
 
 
 def norm_add_norm_act(a, gamma_a, beta_a, b, gamma_b, beta_b, kind, act_kind=ACT_NONE, slope=0.0, eps_a=1e-5, eps_b=1e-5,
@@ -1055,7 +1113,7 @@ def norm_add_norm_act(a, gamma_a, beta_a, b, gamma_b, beta_b, kind, act_kind=ACT
     if b_half and kind != NORM_BATCH:
         raise _lib.SempyrError("norm_add_norm_act: a half-resolution branch is only defined for BatchNorm")
     return _apply(_NormAddNormAct, a, gamma_a, beta_a, state_a, b, gamma_b, beta_b, state_b, kind, act_kind, slope, eps_a, eps_b,
-                  b_half)
+                  b_half, tile_stats_of(a) if kind == NORM_BATCH else None)
 
 
 class _AffineRowAct(Function):

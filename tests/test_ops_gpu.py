@@ -251,6 +251,84 @@ def test_stem_wgrad_entry_point(dev):
     assert none is None and torch.equal(gw3, gw)
 
 
+# (B, Cin, H, W, Cout, ups): 3x3 s1 p1 bias-free convolutions in front of a training-mode BatchNorm (generator.py:41-43)
+STATS_CASES = [
+    (2, 64, 32, 32, 64, 0),      # 64x64 tiles would be too few: whichever configuration the plan picks
+    (4, 64, 64, 64, 64, 0),      # 64 x 128 / 64 x 256 tiles: 64-pixel groups
+    (2, 128, 16, 16, 64, 1),     # fused nearest x2 upsample
+    (2, 64, 16, 16, 256, 0),
+    (16, 64, 32, 32, 128, 0),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_epilogue_batchnorm_statistics(dev, case):
+    """sempyr_conv2d_fwd_stats + sempyr_bn_stats_from_tiles against conv -> BatchNorm2d(train) -> ReLU in torch: output,
+    running statistics, and every gradient; and bit-identical y to the plain convolution."""
+    ops = _ops()
+    B, Cin, H, W, Cout, ups = case
+    g = torch.Generator().manual_seed(21 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    w[0] += 0.02          # a channel whose mean is far from zero relative to its spread
+    gam = torch.rand(Cout, generator=g) + 0.5; bet = torch.randn(Cout, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    gr = gam.clone().requires_grad_(True); br = bet.clone().requires_grad_(True)
+    rm_r = torch.zeros(Cout); rv_r = torch.ones(Cout)
+    xin = F.interpolate(xr, scale_factor=2, mode='nearest') if ups else xr
+    pre = F.conv2d(xin, wr, None, 1, 1)
+    # (no activation here: a ReLU element at round-off distance from zero may fall on the other side in either
+    # implementation and the max-norm gradient comparison below would measure that, not the kernels; the ReLU epilogue of the
+    # apply pass is compared forward-only at the end)
+    yr = F.batch_norm(pre, rm_r, rv_r, gr, br, True, 0.1, 1e-5)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
+    gd = gam.to(dev).requires_grad_(True); bd = bet.to(dev).requires_grad_(True)
+    rm = torch.zeros(Cout, device=dev); rv = torch.ones(Cout, device=dev); nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    plan = ops.get_plan((B, Cin, H, W, Cout, 3, 3, 1, 1, ups), xd.device)
+    granule = ops.conv_stats_granule(plan)
+    pre_d = ops.conv2d(xd, wd, None, 1, 1, upsample=bool(ups), stats=True)
+    if granule:
+        ts, gr_ = ops.tile_stats_of(pre_d)
+        assert gr_ == granule and ts.numel() == 2 * B * Cout * (pre_d.shape[2] * pre_d.shape[3] // granule)
+        # the partial sums themselves: group sums and squared deviations, exactly what they claim to be
+        v = pre_d.detach().double().reshape(B * Cout, -1, granule).cpu()
+        tsd = ts.reshape(B * Cout, -1, 2).double().cpu()
+        assert float((tsd[..., 0] - v.sum(-1)).abs().max()) < 1e-3
+        m2 = ((v - v.mean(-1, keepdim=True)) ** 2).sum(-1)
+        assert float(((tsd[..., 1] - m2).abs() / (m2.abs() + 1e-3)).max()) < 1e-4
+    else:
+        assert ops.tile_stats_of(pre_d) is None
+    with torch.no_grad():
+        plain = ops.conv2d(xd, wd, None, 1, 1, upsample=bool(ups))
+    assert torch.equal(plain, pre_d.detach())
+    y = ops.norm_act(pre_d, gd, bd, ops.NORM_BATCH, ops.ACT_NONE, 0.0, 1e-5, (rm, rv, nbt, 0.1))
+    y.backward(gy.to(dev))
+    tol = 3e-5
+    assert rel_err(y, yr) < tol
+    assert rel_err(rm, rm_r) < tol and rel_err(rv, rv_r) < tol and int(nbt) == 1
+    assert rel_err(xd.grad, xr.grad) < 1e-4
+    assert rel_err(wd.grad, wr.grad) < 1e-4
+    assert rel_err(gd.grad, gr.grad) < 1e-4 and rel_err(bd.grad, br.grad) < 1e-4
+    with torch.no_grad():
+        y2 = ops.norm_act(pre_d.detach(), gd, bd, ops.NORM_BATCH, ops.ACT_RELU, 0.0, 1e-5, None) if not granule else \
+            ops._apply(ops._NormAct, pre_d.detach(), gd.detach(), bd.detach(), ops.NORM_BATCH, ops.ACT_RELU, 0.0, 1e-5, None,
+                       ops.tile_stats_of(pre_d))
+    assert rel_err(y2, F.relu(yr)) < tol
+
+
+def test_conv_epilogue_statistics_cover_the_generator(dev):
+    """The shapes the statistics epilogue is for: every 3x3 convolution of the res generator at 64x64 and above reports a
+    granule (so the training loop does not fall back to the separate statistics pass unnoticed)."""
+    ops = _ops()
+    d = torch.device(dev)
+    for key in [(16, 64, 128, 128, 64, 3, 3, 1, 1, 1), (16, 64, 256, 256, 64, 3, 3, 1, 1, 0), (16, 64, 64, 64, 64, 3, 3, 1, 1, 1),
+                (16, 64, 128, 128, 64, 3, 3, 1, 1, 0), (16, 128, 32, 32, 64, 3, 3, 1, 1, 1), (16, 64, 64, 64, 64, 3, 3, 1, 1, 0)]:
+        assert ops.conv_stats_granule(ops.get_plan(key, d)) in (32, 64), key
+
+
 NORM_KINDS = ['batch', 'instance', 'layer']
 
 
