@@ -210,11 +210,16 @@ def main():
                           "conv_launches": int(kl.value), "conv_ms_hip_events": kms.value, "conv_gflop_2MNK": kf.value * 1e-9}), flush=True)
         return
     barrier()
+    mark = os.environ.get('SEMPYR_MARK_TIMED', '0') == '1'        # tools/busy_union.py: brackets the timed region in a kernel trace
+    if mark:
+        _lib.check(_lib.lib.sempyr_profile_marker(1, torch.cuda.current_stream().cuda_stream), "sempyr_profile_marker")
     c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         cycle()
     host_issue = time.perf_counter() - t0          # all launches issued (GPU may still be running)
+    if mark:
+        _lib.check(_lib.lib.sempyr_profile_marker(2, torch.cuda.current_stream().cuda_stream), "sempyr_profile_marker")
     barrier()
     elapsed = time.perf_counter() - t0
     cpu_time = time.process_time() - c0

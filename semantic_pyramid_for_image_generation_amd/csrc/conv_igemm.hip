@@ -122,9 +122,13 @@ struct IgemmParams {
 // indices of a GATHER chunk (resp. the consecutive columns a WGRAD thread owns) share one filter tap: the bounds test
 // and the spatial offset are computed once per chunk and every load is base + per-channel constant. Without it
 // (RGB stems, Cin = 3) each element is decoded separately.
-template <int BM, int BN, int WM, int WN, int MODE, bool UT>
+template <int BM, int BN, int WM, int WN, int MODE, bool UT, int BKT = 16>
 __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams p)
 {
+    // k-chunk per barrier: 16, or 32 for uniform-tap GATHER launches whose channel count allows it (half the barriers and
+    // staging round trips per MFMA; the host passes chunk counts in units of BKT)
+    constexpr int BK = BKT;
+    static_assert(BKT == 16 || (MODE == MODE_GATHER && UT), "the 32-deep chunk is a uniform-tap GATHER form");
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int PAD = (MODE == MODE_WGRAD) ? (UT ? 1 : 2) : 0;
     constexpr int LDA = BM + PAD, LDB = BN + PAD;
@@ -1465,7 +1469,20 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT>), grid, dim3(256), 0, st, pp);
+    bool deep = false;
+    if constexpr (MODE == MODE_GATHER && UT && BM == 64 && (BN == 64 || BN == 128 || BN == 256)) {
+        static const int mask = env_int("SEMPYR_BK32", 3);           // bit 0: 64x64 tiles, 1: 64x128, 2: 64x256
+        const int bit = BN == 64 ? 1 : (BN == 128 ? 2 : 4);
+        deep = (mask & bit) && p.C % 32 == 0 && pp.nchunks % 2 == 0;
+        for (int i = 0; deep && pp.nphases > 1 && i < pp.nphases; ++i) deep = pp.ph[i].nchunks % 2 == 0;
+        if (deep) {
+            pp.nchunks /= 2;
+            pp.chunks_per_split = (pp.nchunks + splits - 1) / splits;
+            for (int i = 0; i < pp.nphases && pp.nphases > 1; ++i) pp.ph[i].nchunks /= 2;
+            hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT, 32>), grid, dim3(256), 0, st, pp);
+        }
+    }
+    if (!deep) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT>), grid, dim3(256), 0, st, pp);
     if (e1) (void)hipEventRecord(e1, st);
     SEMPYR_CHECK_LAUNCH();
     return 0;
