@@ -13,8 +13,10 @@
  *   - plain pointers and sizes only; all device buffers (workspace included) are owned by the
  *     caller; nothing is allocated or freed here; no host synchronisation; kernels are enqueued
  *     on the hipStream_t passed as `void* stream` (0 = the null stream).
- *   - tensors are fp32, NCHW, contiguous. Element counts must be < 2^31.
- *   - stateless and re-entrant (the autograd worker thread calls the backward entry points).
+ *   - tensors are fp32, NCHW, contiguous. Element counts must be < 2^31; the operands of the convolution family must in
+ *     addition be smaller than 2 GiB each (2^29 elements: their gathers are buffer loads with 32-bit byte offsets; checked).
+ *   - re-entrant (the autograd worker thread calls the backward entry points); the only state is the per-device address
+ *     of sempyr_gp_fwd_static's scratch array and the optional launch profiler (sempyr_profile_*).
  */
 #ifndef SEMPYR_H
 #define SEMPYR_H
