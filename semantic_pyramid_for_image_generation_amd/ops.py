@@ -173,8 +173,10 @@ def _stash(param, g):
 
 
 def flush_param_grads():
-    """param.grad (+)= g for every collected pair, in collection order, with one launch per 64 pairs on the current stream
-    (every producer stream has been joined by the backward pass / join_side_streams by now)."""
+    """param.grad (+)= the collected gradients of every parameter, summed in production order: one launch per 32 parameters
+    (up to four contributions each; a parameter with more goes into a later launch, so no two items of a launch share a
+    destination) on the current stream, which first waits for every stream a contribution was produced on (no
+    AccumulateGrad node runs for these gradients, so the autograd engine joins nothing)."""
     if not _PENDING:
         return
     pend = list(_PENDING)
