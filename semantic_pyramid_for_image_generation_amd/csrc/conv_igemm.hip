@@ -1470,9 +1470,10 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
     }
     if (e0) (void)hipEventRecord(e0, st);
     bool deep = false;
-    if constexpr (MODE == MODE_GATHER && UT && BM == 64 && (BN == 64 || BN == 128 || BN == 256)) {
-        static const int mask = env_int("SEMPYR_BK32", 3);           // bit 0: 64x64 tiles, 1: 64x128, 2: 64x256
-        const int bit = BN == 64 ? 1 : (BN == 128 ? 2 : 4);
+    if constexpr (MODE == MODE_GATHER && UT && BM == 64 && (BN == 64 || BN == 128)) {
+        // (64x256 tiles were measured too: 80 KB of LDS leave 2 workgroups per CU and the cycle got 0.3 ms slower)
+        static const int mask = env_int("SEMPYR_BK32", 3);           // bit 0: 64x64 tiles, 1: 64x128
+        const int bit = BN == 64 ? 1 : 2;
         deep = (mask & bit) && p.C % 32 == 0 && pp.nchunks % 2 == 0;
         for (int i = 0; deep && pp.nphases > 1 && i < pp.nphases; ++i) deep = pp.ph[i].nchunks % 2 == 0;
         if (deep) {
