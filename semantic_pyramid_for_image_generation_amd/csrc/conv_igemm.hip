@@ -593,8 +593,13 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
 
     // tile geometry (uniform): first output pixel, patch origin in source coordinates
     const int tb = n0 / p.QHW;
-    const int tr = n0 - tb * p.QHW;
-    const int gy0 = tr / p.QW, gx0 = tr - gy0 * p.QW;
+    // the tile is a block of BN / CW rows x CW columns of sample tb (CW == QW: whole rows; CW == BN: a row segment; in
+    // between: a 2-D block, whose input patch -- (R+2) x (CW+2) -- is the smaller the squarer it is: 4 x 64 pixels stage
+    // 396 source pixels per channel where 1 x 256 stages 774 and re-reads every input row three times)
+    const int tt = (n0 - tb * p.QHW) / BN;                  // tile index inside the sample
+    const int tpr = p.QW / p.CW;                            // tiles per row of blocks
+    const int trow = tt / tpr, tcol = tt - trow * tpr;
+    const int gy0 = trow * (BN / p.CW), gx0 = tcol * p.CW;
     const int s = p.ups;
     const int pr0 = (gy0 - 1) >> s, pc0 = (gx0 - 1) >> s;
     const int PW = p.PW, PRPW = p.PR * p.PW;
@@ -760,8 +765,8 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
     if (p.res) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-            const int rr = n - tb * p.QHW, ry = rr / p.QW, rx = rr - ry * p.QW;
+            const int nl = wn * (TN * 32) + j * 32 + l31;
+            const int ry = gy0 + nl / p.CW, rx = gx0 + nl % p.CW, rr = ry * p.QW + rx;
             const float* rp = p.res_half ? p.res + (size_t)tb * (p.OCHW >> 2) + (ry >> 1) * (p.OW >> 1) + (rx >> 1)
                                          : p.res + (size_t)tb * p.OCHW + rr;
             const int rstride = p.res_half ? (p.OHW >> 2) : p.OHW;
@@ -789,7 +794,9 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
         // closed by a 32-lane butterfly: quad permutes, the two row mirrors and a swizzle across the 16-lane rows.
         constexpr int GR = TN * 32;
         const int G = p.QHW / GR;
-        const int g = tr / GR + wn;                         // BN % GR == 0 and the tile starts at pixel tr of the plane
+        // the wave's TN*32 columns are GR consecutive pixels of one row of the block (CW % GR == 0)
+        const int nl0 = wn * GR;
+        const int g = ((gy0 + nl0 / p.CW) * p.QW + gx0 + nl0 % p.CW) / GR;
         auto sum32 = [](float v) {
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
@@ -819,8 +826,8 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-        const int r = n - tb * p.QHW;                        // the tile lies inside sample tb
+        const int nl = wn * (TN * 32) + j * 32 + l31;
+        const int r = (gy0 + nl / p.CW) * p.QW + gx0 + nl % p.CW;        // the tile lies inside sample tb
         float* op = out + (size_t)tb * p.OCHW + r;           // stride-1 output: OHW == QHW, pixel r of the plane
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -1581,7 +1588,9 @@ inline bool patch3x3_ok(const sempyr_conv_desc* d, int mode, int bm, int bn, Ige
     if (mode == SEMPYR_CONV_DGRAD && d->ups) return false;
     if (p.Mpad % bm != 0 || p.N % bn != 0 || p.QHW % bn != 0) return false;      // tiles are whole and inside one sample
     int R, CW;
-    if (bn % p.QW == 0) { R = bn / p.QW; CW = p.QW; }
+    static const int blk = env_int("SEMPYR_PATCH_BLOCK", 64);   // columns of a 2-D tile block (0: whole rows / row segments only)
+    if (blk >= 64 && blk % 64 == 0 && p.QW > blk && p.QW % blk == 0 && bn % blk == 0 && p.QH % (bn / blk) == 0) { R = bn / blk; CW = blk; }
+    else if (bn % p.QW == 0) { R = bn / p.QW; CW = p.QW; }
     else if (p.QW % bn == 0) { R = 1; CW = bn; }
     else return false;
     const int s = p.ups;
@@ -1704,7 +1713,7 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         if (plan->splits[0] == 1 && !rgb3x3_ok(d, mode) && N < (1ll << 31)) {
             // would the patch kernel take it?  (the geometry fields its eligibility test reads)
             IgemmParams q{};
-            q.Mpad = plan->Mpad; q.N = (int)N; q.QHW = g.Ho * g.Wo; q.QW = g.Wo; q.ups = d->ups;
+            q.Mpad = plan->Mpad; q.N = (int)N; q.QHW = g.Ho * g.Wo; q.QW = g.Wo; q.QH = g.Ho; q.ups = d->ups;
             const int eff = patch_effective_cfg(d, mode, plan->cfg, q, 1);
             if (eff >= 0 && (g.Ho * g.Wo) % patch_stats_granule(eff) == 0) plan->stats_granule = patch_stats_granule(eff);
         }

@@ -191,21 +191,35 @@ __global__ __launch_bounds__(256) void bn_tile_finalize_kernel(const float2* __r
     const int c = blockIdx.x, t = threadIdx.x;
     const int P = N * G;
     const float inv_gr = 1.f / (float)granule;
+    // four independent loads in flight per thread and pass (a dependent chain of P / 256 L2 round trips took 27 us for the
+    // 16384 groups of a 256x256 layer)
+    auto at = [&](int i) -> const float2* { const int b = i / G; return tiles + ((size_t)b * C + c) * G + (i - b * G); };
     float s[1] = {0.f};
-    for (int i = t; i < P; i += 256) {
-        const int b = i / G, g = i - b * G;
-        s[0] += tiles[((size_t)b * C + c) * G + g].x;
+    {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = t;
+        for (; i + 768 < P; i += 1024) {
+            const float a0 = at(i)->x, a1 = at(i + 256)->x, a2 = at(i + 512)->x, a3 = at(i + 768)->x;
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; i < P; i += 256) s0 += at(i)->x;
+        s[0] = (s0 + s1) + (s2 + s3);
     }
     row_reduce<256, 1>(s, sh);
     const float m = (float)P * (float)granule;
     const float mean = s[0] / m;
     __syncthreads();
     float q[1] = {0.f};
-    for (int i = t; i < P; i += 256) {
-        const int b = i / G, g = i - b * G;
-        const float2 v = tiles[((size_t)b * C + c) * G + g];
-        const float d = v.x * inv_gr - mean;
-        q[0] += v.y + (float)granule * d * d;
+    {
+        auto term = [&](float2 v) { const float d = v.x * inv_gr - mean; return v.y + (float)granule * d * d; };
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        int i = t;
+        for (; i + 768 < P; i += 1024) {
+            const float2 v0 = *at(i), v1 = *at(i + 256), v2 = *at(i + 512), v3 = *at(i + 768);
+            q0 += term(v0); q1 += term(v1); q2 += term(v2); q3 += term(v3);
+        }
+        for (; i < P; i += 256) q0 += term(*at(i));
+        q[0] = (q0 + q1) + (q2 + q3);
     }
     row_reduce<256, 1>(q, sh);
     const float m2 = q[0];
