@@ -172,10 +172,13 @@ def main():
                         executor='hip' if a.loop_mode == 'hipgraph' else 'own')
     it = [0]
 
+    layers = []
+
     def cycle():
         for _ in range(5):
             it[0] += 1
             lp.iteration(pool[it[0] % len(pool)])
+            layers.append(lp.features_to_train)
 
     def barrier():
         if world > 1:
@@ -213,6 +216,7 @@ def main():
     mark = os.environ.get('SEMPYR_MARK_TIMED', '0') == '1'        # tools/busy_union.py: brackets the timed region in a kernel trace
     if mark:
         _lib.check(_lib.lib.sempyr_profile_marker(1, torch.cuda.current_stream().cuda_stream), "sempyr_profile_marker")
+    del layers[:]
     c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -223,6 +227,29 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     cpu_time = time.process_time() - c0
+    timed_layers = list(layers)
+    # The same K steps without the two exact shortcuts that rest on the reference's all-zero masks (quirk Q2: no convolution of
+    # a zero-masked tap, no classifier layer behind the deepest tap with a non-zero mask).  Results are bit-identical either
+    # way (tests/test_graph_loop_gpu.py::test_exact_shortcuts_change_nothing); reported so that either number can be quoted.
+    from semantic_pyramid_for_image_generation_amd import generator as gmod
+    plain = None
+    if (gmod.ZERO_SKIP or tm.DEAD_TAPS) and a.loop_mode == 'eager' and not a.profile_pass:
+        saved_sc = (gmod.ZERO_SKIP, tm.DEAD_TAPS)
+        gmod.ZERO_SKIP, tm.DEAD_TAPS = False, False
+        rs = random.getstate()
+        cycle()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            cycle()
+        barrier()
+        plain = time.perf_counter() - t1
+        gmod.ZERO_SKIP, tm.DEAD_TAPS = saved_sc
+        random.setstate(rs)
+        if world > 1:
+            t = torch.tensor([plain], dtype=torch.float64, device='cpu' if torch.distributed.get_backend() == 'gloo' else device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            plain = float(t.item())
     # Kernel durations for the roofline: the SAME K steps run once more with a HIP event pair around every conv launch
     # (recorded on the launch's own stream).  They are not recorded during the headline pass because an event pair per
     # launch keeps consecutive kernels from overlapping (measured: +4 % on the cycle time); `instrumented_ms_per_step`
@@ -291,8 +318,15 @@ def main():
                                    f"{a.discriminator_norm}, GP weight 10, batch {B}/GPU, 256x256"
                                    + (", diversity loss" if a.use_diversity_loss else ""),
                        "iters_per_step": 5, "batch_per_gpu": B, "parallelism": f"dp{world}", "loop_mode": a.loop_mode,
-                       "weights": "seeded random init (trained blobs are not shipped)"},
+                       "weights": "seeded random init (trained blobs are not shipped)",
+                       "layers_drawn_in_timed_steps": {str(k): timed_layers.count(k) for k in (1, 2, 3, 4)}},
         }
+        if plain is not None:
+            out["exact_shortcuts"] = {
+                "what": "taps / feature-branch convolutions that the reference multiplies by all-zero masks (quirk Q2, "
+                        "train_model.py:197-209) are not computed: generator._ZeroConv, train_model.live_taps; outputs, losses and "
+                        "parameter updates are bit-identical with and without (tests/test_graph_loop_gpu.py)",
+                "value_without": iters * world / plain, "ms_per_step_without": 1000.0 * plain / a.steps}
         if eval_ips is not None:
             out["eval_images_per_sec"] = eval_ips
             out["eval_config"] = "eval_model.py loop, gen-type res, batch 8, 4 levels x 4 noises, classifier pass included, 10 repetitions"

@@ -36,7 +36,21 @@ class Classifier(nn.Module):
         if geom != (3, 2, 1):
             raise NotImplementedError(f"stem max-pool {geom} has no HIP kernel (ResNet uses 3/2/1)")
 
-    def forward(self, inputs):
+    def forward(self, inputs, taps_upto=None):
+        """(logits, [relu, layer1, layer2, layer3, layer4, avgpool]) as the reference's Classifier (classifier.py:32-44).
+        `taps_upto` (0..4, optional): the caller consumes no tap deeper than `layer<taps_upto>` (train_model.live_taps: the
+        reference multiplies every deeper tap by an all-zero mask, quirk Q2) -- the layers behind it are not run and their
+        taps, the pooled vector and the logits come back as None.  0: nothing is consumed, nothing runs."""
+        if taps_upto is not None:
+            if not 0 <= taps_upto <= 4:
+                raise ValueError("taps_upto must be in 0..4")
+            taps = [None] * 6
+            if taps_upto >= 1:
+                x = ops.max_pool3s2(run_conv_norm(self.conv1, self.bn1, inputs, ops.ACT_RELU))
+                for level in range(1, taps_upto + 1):
+                    x = getattr(self, f'layer{level}')(x)
+                    taps[level] = x
+            return None, taps
         relu = run_conv_norm(self.conv1, self.bn1, inputs, ops.ACT_RELU)
         maxpool = ops.max_pool3s2(relu)
         layer1 = self.layer1(maxpool)

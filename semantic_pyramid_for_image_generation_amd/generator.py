@@ -101,10 +101,13 @@ class GeneratorBlock(nn.Module):
         if mask is not None:
             if (ZERO_SKIP and getattr(mask, '_sempyr_all_zero', False) and block[0].bias is None
                     and isinstance(block[1], nn.BatchNorm2d) and block[1].training):
-                B, _, H, W = features.shape
-                y = ops.zero_conv_output(block[0].weight, (B, block[0].out_channels, 2 * H, 2 * W))
+                # the feature branch has the generator branch's shape (both are summed below); the tap itself is not read
+                # and may be absent (Classifier.forward(..., taps_upto))
+                y = ops.zero_conv_output(block[0].weight, (gen.shape[0], block[0].out_channels, gen.shape[2], gen.shape[3]))
                 kind, slope = activation_kind(block[2])
                 return ops.add_act(gen, run_norm(block[1], y, kind, slope))
+            if features is None:
+                raise ValueError("GeneratorBlock: the classifier tap of this level was not computed but its mask is not all-zero")
             features = ops.mul(features, mask)
         features = self.features_conv_block(features, upsample=(self.gen_type == 'res'))
         return ops.add_act(gen, features)

@@ -179,10 +179,14 @@ class TrainLoop:
                 inp = self._draw_device(key, images, static=False)
                 pf.hand_over(inp.alpha, inp.z_g, inp.z2)
             images_d = self.normalizer_d(inp.images)
-            with torch.no_grad():
-                _, features = self.C(self.normalizer_clf(inp.images))
             ops.build_masks(inp.masks[1:5], inp.spec_dev[6:30])
             masks = [None] + [tm.tag_mask(inp.masks[i], self.specs[i]) for i in range(1, 5)] + [None]
+            upto = tm.live_taps(masks)          # taps behind it are multiplied by all-zero masks wherever they are used
+            with torch.no_grad():
+                if upto is None:
+                    _, features = self.C(self.normalizer_clf(inp.images))
+                else:
+                    _, features = self.C(self.normalizer_clf(inp.images), taps_upto=upto) if upto else (None, [None] * 6)
             fake = tm.fake_for_discriminator(self.G, B, features, masks, z=inp.z_d)
             pf.hand_over(images_d, features, masks[1:5], fake)
             fake_g = None

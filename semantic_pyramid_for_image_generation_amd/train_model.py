@@ -203,6 +203,34 @@ class _frozen:
             p.requires_grad_(True)
 
 
+DEAD_TAPS = os.environ.get("SEMPYR_DEAD_TAPS", "1") != "0"
+
+
+def live_taps(masks):
+    """Deepest classifier tap (1..4) whose mask is not known to be all-zero; 0 when every mask is.  The reference multiplies
+    the taps at and above the drawn layer by all-zero masks (quirk Q2: train_model.py:197-209) both where the generator reads
+    them (generator.py:126-129) and in the feature loss (train_model.py:212-222), so nothing deeper than this level can
+    change any result: the classifier need not compute it (Classifier.forward(..., taps_upto)).  None: shortcut off, or a
+    mask carries no tag (masks built by other means): compute everything."""
+    if not DEAD_TAPS:
+        return None
+    live = 0
+    for i in range(1, 5):
+        m = masks[i]
+        if m is None or not hasattr(m, '_sempyr_all_zero'):
+            return None
+        if not m._sempyr_all_zero:
+            live = i
+    return live
+
+
+def _device_of(features, masks):
+    for t in list(features) + list(masks):
+        if t is not None:
+            return t.device
+    raise ValueError("no tensor to take the device from")
+
+
 def train_generator(generator, discriminator, generator_loss_fn, generator_optimizer, batch_size, features, criterion_features,
                     features_to_train, classifier, normalizer_clf, criterion_diversity_n, criterion_diversity_d, masks,
                     train_type, epsilon=10e-4, z=None, z2=None, fake_images=None):
@@ -210,7 +238,7 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
     drawn on the device generator as in the reference.  `fake_images`: the step's own forward `generator(z, features,
     masks)` WITH its autograd graph, computed ahead by the caller (`fake_for_generator` inside a `prefetch` block: that
     forward does not depend on the critic step in front of it); `z` must then be the noise it was made from."""
-    device = features[1].device
+    device = _device_of(features, masks)
     _ensure_train(generator)
     _ensure_train(discriminator)
     if fake_images is not None and z is None:
@@ -234,9 +262,14 @@ def train_generator(generator, discriminator, generator_loss_fn, generator_optim
         else:
             generator_loss = generator_loss_fn(discriminator(fake_images))
 
-        fake_images_clf = normalizer_clf(fake_images)
-        _, fake_features = classifier(fake_images_clf)
-        features_loss = getLossByTrainType(features, masks, train_type, features_to_train, fake_features, criterion_features)
+        upto = live_taps(masks) if train_type != 1 else None
+        if upto == 0:
+            # every level of the feature loss is masked to zero: the loss is exactly 0 with an exactly-zero gradient
+            features_loss = ops.full_like(generator_loss, 0.0)
+        else:
+            fake_images_clf = normalizer_clf(fake_images)
+            _, fake_features = classifier(fake_images_clf) if upto is None else classifier(fake_images_clf, taps_upto=upto)
+            features_loss = getLossByTrainType(features, masks, train_type, features_to_train, fake_features, criterion_features)
         if two_stream:
             main.wait_stream(side)
             generator_loss.record_stream(main)
@@ -336,13 +369,13 @@ def fake_for_generator(generator, features, masks, z):
     """The generator step's own forward (reference train_model.py:93), with its autograd graph, for a caller that runs it
     ahead of the critic step inside a `prefetch` block; pass the result and `z` to train_generator."""
     _ensure_train(generator)
-    _wait_for_generator_update(generator, features[1].device)
+    _wait_for_generator_update(generator, _device_of(features, masks))
     return generator(z, features, masks)
 
 
 def fake_for_discriminator(generator, batch_size, features, masks, z=None):
     """The detached generator forward of a critic step (reference train_model.py:125-126): z from the CPU generator."""
-    device = features[1].device
+    device = _device_of(features, masks)
     _ensure_train(generator)
     if z is None:
         z = _cpu_randn_to(device, batch_size, 128, 1, 1)
@@ -566,7 +599,12 @@ def getLossByTrainType(features, masks, train_type, features_to_train, outputs_i
     if train_type == 1:
         terms = [criterion_features(features[features_to_train], outputs_images_features[features_to_train])]
     else:
-        terms = [term(i) for i in range(1, features_to_train + 1)]
+        # a level whose mask is all zeros contributes |f*0 - g*0| = 0 exactly: when its taps were not computed
+        # (live_taps) the term is left out, which leaves the sum bit for bit what it was (x + 0 = x)
+        terms = [term(i) for i in range(1, features_to_train + 1)
+                 if not (features[i] is None or outputs_images_features[i] is None)]
+        if not terms:
+            raise ValueError("getLossByTrainType: no classifier tap was computed for any level of the loss")
     if all(t.is_cuda for t in terms):
         return ops.lincomb(terms, None, 1 / features_to_train, 200.0)        # (sum * (1/L)) * 200 in one launch
     loss_features = terms[0]
@@ -662,7 +700,8 @@ def _main():
             out = loop.iteration(images, log=writer is not None)
             if first_iter and rank == 0:
                 first_iter = False
-                features = out['features']
+                with torch.no_grad():       # every tap of the first batch (the loop only computes the taps an iteration reads)
+                    _, features = classifier(normalizer_clf(images))
                 images_discriminator = out['images_d']
                 fixed_features = [torch.clone(f) for f in features]
                 fixed_masks = [torch.ones(f.shape, device=device) for f in features]

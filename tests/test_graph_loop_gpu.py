@@ -59,7 +59,7 @@ def test_replay_bit_identical_to_eager(dev, executor):
     assert len(lp.graphs) == 8                                  # (generator step or not) x layer 1..4, all captured by prepare()
     if executor == 'own':
         stats = lp.graphs[(False, False, 1)].stats
-        assert stats[0] > 300 and stats[2] == 0 and stats[4] >= 2      # kernels; no memcpy nodes; more than one stream
+        assert stats[0] > 200 and stats[2] == 0 and stats[4] >= 2      # kernels; no memcpy nodes; more than one stream
     assert [it for it, _ in le] == list(range(1, 8))
     for (ia, a), (ib, b) in zip(le, lg):
         assert ia == ib and a == b, (ia, a, b)
@@ -87,6 +87,50 @@ def test_replay_batch_norm_critic_and_diversity(dev):
     for k in se:
         assert torch.equal(se[k], sg[k]), k
     assert int(se[('D', 'conv_block1.conv_block1.block.1.num_batches_tracked')]) == 6 * 3 + 2     # 3 critic passes per D step + 1 per G step (iterations 1 and 6)
+
+
+def test_exact_shortcuts_change_nothing(dev):
+    """The two shortcuts that rest on the reference's all-zero masks (quirk Q2) -- no convolution of a zero-masked tap
+    (generator._ZeroConv) and no classifier layer behind the deepest tap with a non-zero mask (train_model.live_taps) -- are
+    exact: 11 iterations (three generator steps, every layer 1..4 drawn) with and without them give the same logged losses
+    and bit-identical generator / critic parameters and BatchNorm buffers."""
+    from semantic_pyramid_for_image_generation_amd import generator as gmod
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    saved = (gmod.ZERO_SKIP, tm.DEAD_TAPS)
+    try:
+        gmod.ZERO_SKIP, tm.DEAD_TAPS = True, True
+        l1, s1, lp = _run(dev, False, 'own', 11, False, B=2)
+        gmod.ZERO_SKIP, tm.DEAD_TAPS = False, False
+        l0, s0, _ = _run(dev, False, 'own', 11, False, B=2)
+    finally:
+        gmod.ZERO_SKIP, tm.DEAD_TAPS = saved
+    assert [d for _, d in l1] == [d for _, d in l0]
+    assert sum(1 for _, d in l1 if 'G/g_loss' in d) == 3
+    for k in s1:
+        assert torch.equal(s1[k], s0[k]), k
+
+
+def test_live_taps_and_partial_classifier(dev):
+    """Classifier.forward(x, taps_upto=k) returns exactly the taps of the full forward up to layer k and None behind it;
+    live_taps reads the deepest non-zero mask from the tags of the mask setters."""
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    G, D, lp = _make(dev, False, B=2)
+    x = recipes.image_batch(5, 2).to(dev)
+    with torch.no_grad():
+        _, full = lp.C(lp.normalizer_clf(x))
+        for k in range(0, 5):
+            out, taps = lp.C(lp.normalizer_clf(x), taps_upto=k)
+            assert out is None and taps[0] is None and taps[5] is None
+            for i in range(1, 5):
+                assert (taps[i] is None) if i > k else torch.equal(taps[i], full[i])
+    random.seed(3)
+    seen = set()
+    for _ in range(40):
+        key = lp.draw()
+        masks = [None] + [tm.tag_mask(torch.empty(0, device=dev), lp.specs[i]) for i in range(1, 5)] + [None]
+        assert tm.live_taps(masks) == key[2] - 1                 # quirk Q2: the masks at and above the drawn layer are zero
+        seen.add(key[2])
+    assert seen == {1, 2, 3, 4}
 
 
 def test_draw_order_matches_reference(dev):
