@@ -283,6 +283,14 @@ int sempyr_build_masks(const sempyr_mask_target* targets, int n, const int32_t* 
 int sempyr_concat(const float* const* srcs_host, const int64_t* numels_host, int n, float* dst, void* stream);
 /* dst[0..n) = value : grad_outputs=torch.ones_like(pred) train_model.py:73 */
 int sempyr_fill_const(float* dst, float value, int64_t n, void* stream);
+
+/* y = a + act(beta[c]), plus the running-statistics update (decay by 1 - momentum, num_batches_tracked += 1; buffers may
+ * be NULL) of a training-mode BatchNorm2d applied to an all-zero input: conv(0) -> BatchNorm2d -> ReLU -> add of a generator
+ * level whose mask is all zero (generator.py:126-129, quirk Q2) as one launch.  Bit for bit what the statistics pass over
+ * the zero tensor, the apply pass and the add give.  Forward only. */
+int sempyr_bn_zero_input_add(const float* a, const float* beta, float* y, int N, int C, int HW, int act, float slope,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                             void* stream);
 /* *out = ((w_0*x_0 + w_1*x_1 + ...) * s1) * s2 on device scalars, products and sums rounded one by one, left to right:
  * the loss arithmetic train_model.py:101-103,112,138 and :222 (`loss * (1/L) * 200`) in one launch. HOST tables. */
 #define SEMPYR_LINCOMB_MAX 6

@@ -95,6 +95,7 @@ SIGNATURES = {
     "sempyr_build_masks": [ctypes.POINTER(MaskTarget), c_int, _P, _P],
     "sempyr_concat": [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int, _P, _P],
     "sempyr_fill_const": [_P, c_float, c_int64, _P],
+    "sempyr_bn_zero_input_add": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_float, _P],
     "sempyr_lincomb": [ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, c_float, c_float, _P, _P],
     "sempyr_accumulate_many": [ctypes.POINTER(AccumItem), c_int, _P],
     "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],

@@ -455,6 +455,37 @@ __global__ __launch_bounds__(256) void accumulate_many_kernel(const AccumArgs a)
     }
 }
 
+// y = a + act(beta[c]) and the running-statistics update of a training-mode BatchNorm2d whose input is all zeros (the
+// feature branch of a generator level whose mask is all zero, generator.py:126-129 with quirk Q2): batch mean and variance
+// are exactly 0, so BN(0) = beta and the buffers decay by (1 - momentum) -- exactly what the statistics pass over the zero
+// tensor, the apply pass and the add would produce, in one launch.
+__global__ __launch_bounds__(256) void add_channel_const_kernel(const float* __restrict__ a, const float* __restrict__ beta,
+                                                                float* __restrict__ y, long long total, int len, int C, int vec,
+                                                                int act, float slope,
+                                                                float* running_mean, float* running_var, long long* nbt, float momentum)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && running_mean) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * 0.f;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * 0.f;
+        }
+        if (threadIdx.x == 0 && nbt) *nbt += 1;
+    }
+    if (vec) {
+        if (i * 4 >= total) return;
+        const int row = (int)((i * 4) / len);
+        const float k = act_apply(beta[row % C], act, slope);
+        float4 v = reinterpret_cast<const float4*>(a)[i];
+        v.x += k; v.y += k; v.z += k; v.w += k;
+        reinterpret_cast<float4*>(y)[i] = v;
+    } else {
+        if (i >= total) return;
+        const int row = (int)(i / len);
+        y[i] = a[i] + act_apply(beta[row % C], act, slope);
+    }
+}
+
 } // namespace
 
 #define LAUNCH_1D(kernel, nthreads, st, ...) do { \
@@ -507,6 +538,20 @@ extern "C" int sempyr_affine_act_bwd(const float* gy, const float* y, const floa
     const long long total = (long long)rows * len;
     const int vec = (len % 4 == 0) && aligned16(gy) && (!y || aligned16(y)) && (!gx || aligned16(gx)) && (!gres || aligned16(gres));
     LAUNCH_1D(affine_act_bwd_kernel, vec ? total / 4 : total, (hipStream_t)stream, gy, y, scale_row, gx, gres, total, len, vec, act, slope);
+    return 0;
+}
+
+extern "C" int sempyr_bn_zero_input_add(const float* a, const float* beta, float* y, int N, int C, int HW, int act, float slope,
+                                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                        void* stream)
+{
+    if (!a || !beta || !y || N < 1 || C < 1 || HW < 1) SEMPYR_FAIL("bn_zero_input_add: bad arguments");
+    if (act < SEMPYR_ACT_NONE || act > SEMPYR_ACT_LRELU) SEMPYR_FAIL("bn_zero_input_add: activation must be none / ReLU / LeakyReLU");
+    if ((running_mean == nullptr) != (running_var == nullptr)) SEMPYR_FAIL("bn_zero_input_add: running_mean and running_var come together");
+    const long long total = (long long)N * C * HW;
+    const int vec = (HW % 4 == 0) && aligned16(a) && aligned16(y);
+    LAUNCH_1D(add_channel_const_kernel, vec ? total / 4 : total, (hipStream_t)stream, a, beta, y, total, HW, C, vec, act, slope,
+              running_mean, running_var, (long long*)num_batches_tracked, momentum);
     return 0;
 }
 

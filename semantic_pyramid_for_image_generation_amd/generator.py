@@ -2,6 +2,7 @@
 arguments, `forward` signatures, `init_weights()` and state_dict keys), executed on hand-written HIP
 kernels.  The nearest-x2 upsample of the residual blocks is fused into the gather of the consuming
 convolutions instead of being materialised (reference generator.py:51-52,85)."""
+import torch
 import torch.nn as nn
 
 import os
@@ -103,8 +104,15 @@ class GeneratorBlock(nn.Module):
                     and isinstance(block[1], nn.BatchNorm2d) and block[1].training):
                 # the feature branch has the generator branch's shape (both are summed below); the tap itself is not read
                 # and may be absent (Classifier.forward(..., taps_upto))
-                y = ops.zero_conv_output(block[0].weight, (gen.shape[0], block[0].out_channels, gen.shape[2], gen.shape[3]))
                 kind, slope = activation_kind(block[2])
+                bn = block[1]
+                if (not torch.is_grad_enabled() and kind in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU) and bn.affine
+                        and (not bn.track_running_stats or bn.momentum is not None)):
+                    # detached forward (train_model.py:126): BatchNorm of an all-zero map is its bias, one launch
+                    state = (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)) \
+                        if bn.track_running_stats else None
+                    return ops.bn_zero_input_add(gen, bn.bias, kind, slope, state)
+                y = ops.zero_conv_output(block[0].weight, (gen.shape[0], block[0].out_channels, gen.shape[2], gen.shape[3]))
                 return ops.add_act(gen, run_norm(block[1], y, kind, slope))
             if features is None:
                 raise ValueError("GeneratorBlock: the classifier tap of this level was not computed but its mask is not all-zero")

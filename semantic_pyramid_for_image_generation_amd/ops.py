@@ -883,6 +883,26 @@ class _ZeroConv(Function):
         return gw, None
 
 
+def bn_zero_input_add(a, beta, act_kind=ACT_NONE, slope=0.0, bn_state=None):
+    """a + act(BatchNorm2d(0)) for a training-mode BatchNorm whose input is all zeros (sempyr_bn_zero_input_add): the
+    batch statistics are exactly 0, the output is a + act(beta[c]), the running buffers decay.  No autograd."""
+    if torch.is_grad_enabled():
+        raise _lib.SempyrError("bn_zero_input_add is a forward-only helper: call it under torch.no_grad()")
+    a = _req(a, "input"); beta = _req(beta, "norm bias")
+    N, C, HW = _nchw(a)
+    rm = rv = nbt = None
+    momentum = 0.0
+    if bn_state is not None:
+        rm, rv, nbt, momentum = bn_state
+    y = torch.empty_like(a)
+    check(L.sempyr_bn_zero_input_add(a.data_ptr(), beta.data_ptr(), y.data_ptr(), N, C, HW, act_kind, slope, _p(rm), _p(rv), _p(nbt),
+                                     momentum, _stream()), "sempyr_bn_zero_input_add")
+    if bn_state is not None:
+        torch.autograd.graph.increment_version(rm)
+        torch.autograd.graph.increment_version(rv)
+    return y
+
+
 def zero_conv_output(w, shape):
     """conv(zeros, w) for a bias-free convolution: see _ZeroConv."""
     return _apply(_ZeroConv, w, tuple(shape))
