@@ -42,6 +42,10 @@ CONV_CASES = [
     (1, 3, 16, 256, 8, 3, 1, 1, 0, True),       # ... and as an input gradient
     (1, 8, 40, 128, 4, 3, 1, 1, 0, True),       # VALU weight-gradient kernel: 4 output rows, ragged last row strip
     (2, 4, 70, 256, 3, 3, 1, 1, 0, True),       # ... rolling-window path (width 256), three strips
+    (2, 16, 24, 128, 64, 3, 1, 1, 0, False),    # patch kernel on 2-D tile blocks (rows x 64 columns of a wider image)
+    (1, 16, 12, 64, 64, 3, 1, 1, 1, False),     # ... through the fused upsample (24 x 128 output)
+    (1, 8, 16, 256, 32, 3, 1, 1, 0, True),      # ... four blocks per image row, bias
+    (1, 64, 8, 192, 64, 3, 1, 1, 0, False),     # ... width 192 = 3 blocks
 ]
 
 
@@ -327,6 +331,26 @@ def test_conv_epilogue_statistics_cover_the_generator(dev):
     for key in [(16, 64, 128, 128, 64, 3, 3, 1, 1, 1), (16, 64, 256, 256, 64, 3, 3, 1, 1, 0), (16, 64, 64, 64, 64, 3, 3, 1, 1, 1),
                 (16, 64, 128, 128, 64, 3, 3, 1, 1, 0), (16, 128, 32, 32, 64, 3, 3, 1, 1, 1), (16, 64, 64, 64, 64, 3, 3, 1, 1, 0)]:
         assert ops.conv_stats_granule(ops.get_plan(key, d)) in (32, 64), key
+
+
+def test_bn_zero_input_add(dev):
+    """sempyr_bn_zero_input_add against the three passes it replaces: BatchNorm2d(train) of an all-zero map + ReLU, added to
+    another tensor -- output and running buffers bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    for shape in [(3, 8, 6, 10), (2, 64, 16, 16)]:
+        a = torch.randn(*shape, generator=g).to(dev)
+        C = shape[1]
+        gam = (torch.rand(C, generator=g) + 0.5).to(dev); bet = torch.randn(C, generator=g).to(dev)
+        rm1 = torch.randn(C, generator=g).to(dev); rv1 = (torch.rand(C, generator=g) + 0.5).to(dev)
+        n1 = torch.tensor(3, dtype=torch.int64, device=dev)
+        rm2, rv2, n2 = rm1.clone(), rv1.clone(), n1.clone()
+        with torch.no_grad():
+            z = torch.zeros(shape, device=dev)
+            ref = ops.add_act(a, ops.norm_act(z, gam, bet, ops.NORM_BATCH, ops.ACT_RELU, 0.0, 1e-5, (rm1, rv1, n1, 0.1)))
+            out = ops.bn_zero_input_add(a, bet, ops.ACT_RELU, 0.0, (rm2, rv2, n2, 0.1))
+        assert torch.equal(out, ref)
+        assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2) and int(n2) == 4
 
 
 NORM_KINDS = ['batch', 'instance', 'layer']
