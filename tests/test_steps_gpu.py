@@ -195,6 +195,57 @@ def test_g_step_gradients_vs_oracle(dev, case):
     assert all(p.requires_grad for p in D.parameters())         # the temporary freeze was undone
 
 
+def _cosine_and_norms(named_got, ref, names, min_cos, norm_tol):
+    """per tensor: cosine similarity with the oracle gradient and ratio of norms (tensors whose oracle gradient is
+    structurally zero -- a conv bias in front of a norm layer -- are skipped)"""
+    gmax = max(float(ref[k].grad.norm()) for k in names if ref[k].grad is not None)
+    checked = 0
+    worst = (1.0, None)
+    for k in names:
+        want = ref[k].grad
+        if want is None or float(want.norm()) <= 1e-4 * gmax:
+            continue
+        got = named_got[k].detach().double().cpu().flatten()
+        want = want.double().flatten()
+        cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
+        ratio = float(got.norm() / want.norm())
+        assert cos >= min_cos, (k, 'cosine', cos)
+        assert abs(ratio - 1.0) <= norm_tol, (k, 'norm ratio', ratio)
+        if cos < worst[0]:
+            worst = (cos, k)
+        checked += 1
+    assert checked >= 10
+    return worst
+
+
+def test_production_batch_steps_vs_oracle(dev):
+    """The headline configuration at its production batch (res generator, instance_norm critic, batch 16, 256x256): one critic
+    step and one generator step against the fp64 oracle -- losses within 1e-3, every gradient tensor within 0.5 % in norm and
+    with cosine >= 0.9999 (at batch 16 the gradients are well conditioned; the element-wise bound of the batch-2 tests is
+    measured there)."""
+    tm, G, D, C, tr, images, feats, masks, z, z2, alpha = _setup(dev, 'res', 'instance_norm', False, 91, B=16)
+    d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
+    crit = tm.L1Loss()
+    # learning rate 0 on both sides: the generator step that follows sees the critic the oracle's generator step sees
+    tr.d_opt.param_groups[0]['lr'] = 0.0
+    d_opt = _Adam(D.parameters(), lr=0.0, betas=(0.5, 0.999))
+    g_opt = _Adam(G.parameters(), lr=0.0, betas=(0.5, 0.999))
+    real = (images - 0.5) / 0.5
+    want = tr.d_step(_d(real), _d(feats), _d(masks), _d(z), _d(alpha))
+    got = tm.train_discriminator(G, D, d_loss_fn, d_opt, real.to(dev), [f.to(dev) for f in feats],
+                                 [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
+    for k in want:
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _cosine_and_norms({k: p.grad for k, p in D.named_parameters()}, tr.d, tr.d_params, 0.9999, 5e-3)
+    want = tr.g_step(_d(feats), _d(masks), 3, _d(z2))
+    got = tm.train_generator(G, D, g_loss_fn, g_opt, 16, [f.to(dev) for f in feats], crit, 3, C,
+                             tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD), crit, crit, [m.to(dev) for m in masks], [2],
+                             z=z2.to(dev))
+    for k in want:
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _cosine_and_norms({k: p.grad for k, p in G.named_parameters()}, tr.g, tr.g_params, 0.9999, 5e-3)
+
+
 CASES = [('res', 'instance_norm', False), ('res', 'instance_norm', True), ('default', 'batch_norm', False),
          ('default', 'layer_norm', False), ('res', 'batch_norm', False)]
 
