@@ -120,6 +120,25 @@ def cpu_baseline_eval():
                       "extrapolated to 16 forwards = 128 images"}
 
 
+def launch_ranks(n, argv):
+    """Run this script as `n` ranks of one node under torch.distributed.run (RCCL rendezvous on 127.0.0.1, a free port)
+    in a child process; returns its exit code.  stdout / stderr of the ranks pass through (rank 0 prints the line)."""
+    import socket
+    import subprocess
+    if 'SEMPYR_SHARE_GPU' not in os.environ and torch.cuda.device_count() < n:          # (counting devices does not initialise HIP)
+        print(f"bench.py: --gpus {n} but this node shows {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -139,6 +158,11 @@ def main():
                     help='eager: the body is issued from Python on four streams; replay: captured once per variant and re-issued by '
                          'sempyr_replay_launch; hipgraph: captured and replayed by hipGraphLaunch')
     a = ap.parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (one process per GPU) and
+        # relay rank 0's JSON line and the exit code.  This parent never touches the GPU (nothing above initialises HIP) and
+        # never replaces itself: the ranks are children.
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     if os.environ.get('SEMPYR_BENCH_TRACE'):          # debugging aid: where is every thread after N seconds?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['SEMPYR_BENCH_TRACE']), exit=True)
@@ -340,8 +364,9 @@ def main():
                 out["eval_cpu_baseline"] = cpu_baseline_eval()
         if timing and kl.value > 0:
             # algorithmic FLOPs of the launches that ran (2*M*N*K on unpadded dims, summed by the library).  SURVEY 8(d)'s
-            # per-cycle figure is quoted beside it; it is ~4 % higher because convolutions of all-zero feature maps (masks of
-            # levels at or above the selected layer, quirk Q2) are not executed.
+            # per-cycle figure is quoted beside it; the executed count is ~17 % lower (3857 vs 4659 GFLOP per cycle in round 2)
+            # because classifier layers and feature-branch convolutions behind all-zero masks (levels at or above the selected
+            # layer, quirk Q2) are not executed, and the 1x1 skip convolutions run before the upsample.
             achieved = kf.value / (kms.value * 1e-3) / 1e12
             # HBM-side bytes per launch: PMC passes cannot run inside this process; the committed per-kernel summary of the
             # dominant family (tools/pmc_top3.sh -> profiles/r02_top3_traffic.json) is quoted; None if absent.
