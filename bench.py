@@ -179,7 +179,7 @@ def main():
     tm.args = Namespace(use_diversity_loss=a.use_diversity_loss, gradient_penalty_weight=10.0)
     dp = {}
     if world > 1:          # flat gradient buffers: one in-place RCCL all-reduce per optimizer step, 1/N folded into Adam
-        parallel.flatten_grads(G); parallel.flatten_grads(D)
+        parallel.flatten_grads(G); parallel.flatten_grads(D, bucket_bytes=parallel.BUCKET_BYTES)
         dp = dict(grad_scale=1.0 / world, zero_grads=True)
     g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True, **dp)
     d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True, **dp)

@@ -354,7 +354,8 @@ int sempyr_gp_fwd(const float* grad, int rows, int len, float* norms, float* gp,
  * rows > SEMPYR_GP_STATIC_MAX_ROWS is rejected with SEMPYR_ERR_INVALID.  All calls on one GPU share that GPU's array:
  * calls that overlap on one GPU (two streams, two threads) race -- serialise them.  Nothing in the array has to start at
  * zero (each call overwrites every partial it later reads).  The first call on a device looks up the array's device
- * address (hipGetSymbolAddress); make that first call outside stream capture. */
+ * address (hipGetSymbolAddress); make that first call outside stream capture.  The array used is the CURRENT device's: a
+ * non-null `stream` must belong to the current device (checked: SEMPYR_ERR_INVALID otherwise). */
 #define SEMPYR_GP_STATIC_MAX_ROWS 256
 int sempyr_gp_fwd_static(const float* grad, int rows, int len, float* norms, float* gp, void* stream);
 /* out = grad * (*gout) * (2/rows) * (norm-1)/norm : its backward (feeds the double backward) */

@@ -288,6 +288,17 @@ extern "C" int sempyr_gp_fwd_static(const float* grad, int rows, int len, float*
     if (rows > SEMPYR_GP_STATIC_MAX_ROWS)
         SEMPYR_FAIL("gp_fwd_static: %d rows exceed the built-in scratch (SEMPYR_GP_STATIC_MAX_ROWS = %d); use sempyr_gp_fwd "
                     "with a caller-provided scratch buffer", rows, SEMPYR_GP_STATIC_MAX_ROWS);
+    if (stream) {
+        // the scratch array of the CURRENT device is used: a stream of another device would hand its kernels a foreign address
+        hipDevice_t sdev = -1; int cur = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
+            (void)hipGetLastError();
+            SEMPYR_FAIL("gp_fwd_static: cannot determine the device of the stream");
+        }
+        if ((int)sdev != cur)
+            SEMPYR_FAIL("gp_fwd_static: the stream belongs to device %d but device %d is current; make the stream's device current",
+                        (int)sdev, cur);
+    }
     float* scratch = nullptr;
     const int rc = gp_static_scratch_ptr(&scratch);
     if (rc != 0) return rc;

@@ -166,6 +166,17 @@ extern "C" int sempyr_replay_create(void* hip_graph, int max_streams, sempyr_rep
                 sempyr_replay_destroy(r); return SEMPYR_ERR_INVALID;
             }
             s.cp_src = (const char*)p.srcPtr.ptr + p.srcPos.x; s.cp_dst = (char*)p.dstPtr.ptr + p.dstPos.x; s.cp_bytes = p.extent.width;
+            // the copy is re-issued as device-to-device: a node captured with hipMemcpyDefault must really be one
+            for (const void* ptr : {s.cp_src, (const void*)s.cp_dst}) {
+                hipPointerAttribute_t at;
+                hipError_t pe = hipPointerGetAttributes(&at, ptr);
+                if (pe != hipSuccess || at.type != hipMemoryTypeDevice) {
+                    (void)hipGetLastError();
+                    sempyr_set_error("replay_create: memcpy node %d touches memory that is not device memory (only device-to-device "
+                                     "copies are replayed)", (int)i);
+                    sempyr_replay_destroy(r); return SEMPYR_ERR_INVALID;
+                }
+            }
             ++r->n_memcpys;
         } else if (type == hipGraphNodeTypeEmpty) {
             s.kind = K_EMPTY; ++r->n_empty;
@@ -241,10 +252,22 @@ extern "C" int sempyr_replay_create(void* hip_graph, int max_streams, sempyr_rep
     return 0;
 }
 
+static int replay_issue(sempyr_replay* r, hipStream_t main);
+
 extern "C" int sempyr_replay_launch(sempyr_replay* r, void* stream)
 {
     if (!r) { sempyr_set_error("replay_launch: null plan"); return SEMPYR_ERR_INVALID; }
-    hipStream_t main = (hipStream_t)stream;
+    const int rc = replay_issue(r, (hipStream_t)stream);
+    if (rc != 0) {
+        // a launch failed midway: whatever was already issued on the owned streams must not race with what the caller queues
+        // on its stream next (the join at the end was not reached): drain them before returning the error
+        for (size_t st = 1; st < r->streams.size(); ++st) if (r->streams[st]) (void)hipStreamSynchronize(r->streams[st]);
+    }
+    return rc;
+}
+
+static int replay_issue(sempyr_replay* r, hipStream_t main)
+{
     const int ns = (int)r->streams.size();
     if (ns > 1) {
         HIP_TRY(hipEventRecord(r->start, main), "hipEventRecord(start)");

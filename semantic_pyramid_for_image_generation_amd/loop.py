@@ -130,7 +130,7 @@ class TrainLoop:
         is1 = (self.train_type == 1)          # a list never equals 1 (quirk Q1): always the type-2 masks
         crop = None if is1 else (random.randint(20, 40), random.randint(20, 40))
         self.specs = tm.mask_specs(self._tap_shapes(), is1, L, crop)
-        do_g = (it % self.d_steps == 1) or self.d_steps == 1
+        do_g = (it % self.d_steps == 1)          # train_model.py:336 verbatim (never true for discriminator_steps == 1)
         return (do_g, bool(is1), L)
 
     def _draw_device(self, key, images, static):
@@ -233,8 +233,10 @@ class TrainLoop:
             if cap is not None:
                 self._advance_optimizers(key[0])
                 cap.replay(self.device)
-                if key[0]:
-                    tm.mark_generator_updated(self.G, self.device)
+                # every body touches the generator (its train-mode forwards update the BatchNorm running statistics): an
+                # eagerly issued body that follows must not start its generator forward on the prefetch stream before this
+                # one is done, whether or not it ended with a generator step
+                tm.mark_generator_updated(self.G, self.device)
                 out = cap.out
             self.seen.add(key)
         if out is None:

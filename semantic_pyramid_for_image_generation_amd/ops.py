@@ -303,6 +303,12 @@ def _current_stream_obj(device):
     return st
 
 
+# Data parallel (parallel.FlatGrads): called with the weight right after one of its gradient contributions has been issued
+# on the side stream, still with that stream current -- a bucket of the flat gradient buffer whose last contribution this
+# was is all-reduced from here, under the rest of the backward pass.
+_GRAD_ISSUED_HOOK = None
+
+
 def _param_grads_async(gy, x, plan, w, bias, want_w, want_b, bsrc=None):
     """WGRAD(gy, x) -> w.grad and channel_sum(gy) -> bias.grad on the side stream."""
     dev = gy.device
@@ -328,6 +334,8 @@ def _param_grads_async(gy, x, plan, w, bias, want_w, want_b, bsrc=None):
                 _accumulate_grad(bias, _channel_sum_raw(src), main)
             if bsrc is not None:
                 bsrc.record_stream(side)
+        if want_w and _GRAD_ISSUED_HOOK is not None:
+            _GRAD_ISSUED_HOOK(w)
     finally:
         torch.cuda.set_stream(main)
     gy.record_stream(side)
@@ -596,6 +604,8 @@ def _stem_param_grads(g, bits, slope, x, plan, w, bias, want_b):
             _accumulate_grad(w, gw, main)
         if want_b and cur_b is None:
             _accumulate_grad(bias, gb, main)
+        if _GRAD_ISSUED_HOOK is not None:
+            _GRAD_ISSUED_HOOK(w)
     finally:
         torch.cuda.set_stream(main)
     g.record_stream(side)

@@ -659,7 +659,7 @@ def _main():
     if world > 1:
         # data parallel: .grad of every parameter is a view of one persistent flat buffer, summed in place by ONE RCCL
         # all-reduce per optimizer step; Adam reads the sum as a mean (grad_scale) and leaves zeros behind (zero_grads)
-        parallel.flatten_grads(generator); parallel.flatten_grads(discriminator)
+        parallel.flatten_grads(generator); parallel.flatten_grads(discriminator, bucket_bytes=parallel.BUCKET_BYTES)
         dp = dict(grad_scale=1.0 / world, zero_grads=True)
     generator_optimizer = optim.Adam(generator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True, **dp)
     discriminator_optimizer = optim.Adam(discriminator.parameters(), lr=args.lr, betas=(0.5, 0.999), capturable=True, **dp)

@@ -52,7 +52,8 @@ def main():
         p.requires_grad_(False)
     parallel.broadcast_module(G); parallel.broadcast_module(D); parallel.broadcast_module(C)
     tm.args = Namespace(use_diversity_loss=os.environ.get('DP_DIVERSITY', '0') == '1', gradient_penalty_weight=10.0)
-    parallel.flatten_grads(G); parallel.flatten_grads(D)
+    parallel.flatten_grads(G)
+    parallel.flatten_grads(D, bucket_bytes=int(os.environ.get('DP_BUCKET_BYTES', str(8 << 20))))
     dp = dict(grad_scale=1.0 / world, zero_grads=True)
     g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True, **dp)
     d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True, **dp)
@@ -87,7 +88,8 @@ def main():
     torch.save({'rank': rank, 'world': world, 'backend': torch.distributed.get_backend(), 'images': images, 'init': init,
                 'draws': [{k: (cpu(v) if torch.is_tensor(v) else v) for k, v in d.items()} for d in draws],
                 'snaps': snaps, 'logged': [(it, dict(s)) for it, s in logged], 'flat_zero': flat_zero, 'views_ok': views_ok,
-                'device': torch.cuda.current_device()},
+                'device': torch.cuda.current_device(), 'bucket_stats': dict(D._sempyr_flat_grads.stats),
+                'n_buckets': len(D._sempyr_flat_grads.buckets)},
                os.path.join(out_dir, f'rank{rank}.pt'))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

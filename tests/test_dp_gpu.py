@@ -142,7 +142,35 @@ def test_dp_nccl_two_gpus(tmp_path):
     _check(ranks)
 
 
+def _check_buckets(ranks, plain):
+    """The critic's gradient buckets (parallel.FlatGrads): two of them at the default 8 MB, fired from inside the backward pass
+    from the third critic step on (two steps to learn the contribution counts); the result is bit-identical to the single
+    collective after the backward pass."""
+    for rk in ranks:
+        st = rk['bucket_stats']
+        assert rk['n_buckets'] == 2 and st['steps'] == len(rk['snaps'])
+        assert st['early'] == 2 * (st['steps'] - 2) and st['late'] == 2 * 2, st
+    for it, (sa, sb) in enumerate(zip(ranks[0]['snaps'], plain[0]['snaps'])):
+        for m in ('G', 'D'):
+            for k, v in sa[m].items():
+                assert torch.equal(v, sb[m][k]), (it, m, k)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_dp_nccl_buckets_overlap_backward(tmp_path):
+    a = tmp_path / 'a'; b = tmp_path / 'b'
+    a.mkdir(); b.mkdir()
+    ranks = _launch(a, {'SEMPYR_DIST_BACKEND': 'nccl'}, iters=4)
+    plain = _launch(b, {'SEMPYR_DIST_BACKEND': 'nccl', 'DP_BUCKET_BYTES': '0'}, iters=4)
+    _check_buckets(ranks, plain)
+
+
 def test_dp_two_ranks_one_gpu_gloo(tmp_path, dev):
-    ranks = _launch(tmp_path, {'SEMPYR_DIST_BACKEND': 'gloo', 'SEMPYR_SHARE_GPU': '1'})
+    a = tmp_path / 'a'; b = tmp_path / 'b'
+    a.mkdir(); b.mkdir()
+    ranks = _launch(a, {'SEMPYR_DIST_BACKEND': 'gloo', 'SEMPYR_SHARE_GPU': '1'}, iters=4)
     assert all(r['backend'] == 'gloo' for r in ranks)
     _check(ranks)
+    plain = _launch(b, {'SEMPYR_DIST_BACKEND': 'gloo', 'SEMPYR_SHARE_GPU': '1', 'DP_BUCKET_BYTES': '0'}, iters=4)
+    assert plain[0]['n_buckets'] == 0
+    _check_buckets(ranks, plain)
