@@ -192,17 +192,20 @@ def main():
     random.seed(0)                         # identical layer / crop draws on every rank
     # the loop body of train_model.py:300-349 (draws, classifier taps, masks, critic step, generator step every 5th
     # iteration) -- the object train_model._main drives; `--loop-mode` picks how the recorded body is issued
-    lp = loop.TrainLoop(G, D, C, g_opt, d_opt, B, device, use_graphs=(a.loop_mode != 'eager' and world == 1),
-                        executor='hip' if a.loop_mode == 'hipgraph' else 'own')
+    def make_loop():
+        return loop.TrainLoop(G, D, C, g_opt, d_opt, B, device, use_graphs=(a.loop_mode != 'eager' and world == 1),
+                              executor='hip' if a.loop_mode == 'hipgraph' else 'own')
+    lp = make_loop()
     it = [0]
 
     layers = []
 
-    def cycle():
+    def cycle(lp_=None):
+        lp_ = lp_ or lp
         for _ in range(5):
             it[0] += 1
-            lp.iteration(pool[it[0] % len(pool)])
-            layers.append(lp.features_to_train)
+            lp_.iteration(pool[it[0] % len(pool)])
+            layers.append(lp_.features_to_train)
 
     def barrier():
         if world > 1:
@@ -257,17 +260,20 @@ def main():
     # way (tests/test_graph_loop_gpu.py::test_exact_shortcuts_change_nothing); reported so that either number can be quoted.
     from semantic_pyramid_for_image_generation_amd import generator as gmod
     plain = None
-    if (gmod.ZERO_SKIP or tm.DEAD_TAPS) and a.loop_mode == 'eager' and not a.profile_pass:
+    if (gmod.ZERO_SKIP or tm.DEAD_TAPS) and not a.profile_pass:
         saved_sc = (gmod.ZERO_SKIP, tm.DEAD_TAPS)
         gmod.ZERO_SKIP, tm.DEAD_TAPS = False, False
         rs = random.getstate()
-        cycle()
+        lp_plain = make_loop()          # (a captured body has the shortcuts recorded in it: this loop records its own, without)
+        lp_plain.prepare()
+        cycle(lp_plain)
         barrier()
         t1 = time.perf_counter()
         for _ in range(a.steps):
-            cycle()
+            cycle(lp_plain)
         barrier()
         plain = time.perf_counter() - t1
+        del lp_plain
         gmod.ZERO_SKIP, tm.DEAD_TAPS = saved_sc
         random.setstate(rs)
         if world > 1:

@@ -376,6 +376,12 @@ int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float*
  * ---------------------------------------------------------------------------------------- */
 typedef struct sempyr_replay sempyr_replay;
 int sempyr_replay_create(void* hip_graph, int max_streams, sempyr_replay** out, int32_t* stats);
+/* The same, with the first n_side_streams extra streams of the layout supplied by the caller (hipStream_t handles that must
+ * outlive the plan); further ones come from a set the library keeps per device and shares between plans.  HIP maps streams
+ * onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default): a caller that replays on the very streams its eager path
+ * uses keeps concurrently busy streams on distinct queues. */
+int sempyr_replay_create_on(void* hip_graph, int max_streams, void* const* side_streams, int n_side_streams,
+                            sempyr_replay** out, int32_t* stats);
 int sempyr_replay_launch(sempyr_replay* plan, void* stream);
 int sempyr_replay_destroy(sempyr_replay* plan);
 

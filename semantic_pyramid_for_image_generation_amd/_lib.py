@@ -114,6 +114,7 @@ SIGNATURES = {
     "sempyr_gp_bwd": [_P, _P, _P, c_int, c_int, _P, _P],
     "sempyr_channel_sum": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P],
     "sempyr_replay_create": [_P, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32)],
+    "sempyr_replay_create_on": [_P, c_int, ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32)],
     "sempyr_replay_launch": [_P, _P],
     "sempyr_replay_destroy": [_P],
     "sempyr_profile_begin": [c_int],

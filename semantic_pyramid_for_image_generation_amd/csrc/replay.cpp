@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 #include "../../include/sempyr.h"
 
@@ -42,7 +43,7 @@ struct Step {
 
 struct sempyr_replay {
     std::vector<Step> steps;          // in issue order
-    std::vector<hipStream_t> streams; // [0] unused (the caller's stream), others owned
+    std::vector<hipStream_t> streams; // [0] unused (the caller's stream), others from the device's shared set
     std::vector<hipEvent_t> events;
     hipEvent_t start = nullptr;
     std::vector<int> first_on_stream; // step index of the first step of every logical stream (-1: stream unused)
@@ -53,10 +54,35 @@ struct sempyr_replay {
 #define HIP_TRY(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     sempyr_set_error("replay: %s: %s", what, hipGetErrorString(e_)); return (int)e_; } } while (0)
 
+// The extra streams are shared by every plan of a device (plans whose replays overlap are ordered by the events they record,
+// so sharing is always correct): HIP maps streams onto a handful of hardware queues, and a private set per plan -- 16 plans
+// x 3 streams in loop.py -- makes two streams that are busy at the same time share a queue far more often.
+namespace {
+constexpr int REPLAY_MAX_DEVICES = 64;
+std::mutex g_shared_lock;
+std::vector<hipStream_t> g_shared_streams[REPLAY_MAX_DEVICES];
+
+int shared_stream(int idx, hipStream_t* out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= REPLAY_MAX_DEVICES) { sempyr_set_error("replay_create: hipGetDevice"); return SEMPYR_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(g_shared_lock);
+    auto& v = g_shared_streams[dev];
+    while ((int)v.size() <= idx) {
+        hipStream_t st = nullptr;
+        e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) { sempyr_set_error("replay_create: hipStreamCreate: %s", hipGetErrorString(e)); return (int)e; }
+        v.push_back(st);
+    }
+    *out = v[idx];
+    return 0;
+}
+}  // namespace
+
 extern "C" int sempyr_replay_destroy(sempyr_replay* r)
 {
     if (!r) return 0;
-    for (size_t i = 1; i < r->streams.size(); ++i) if (r->streams[i]) (void)hipStreamDestroy(r->streams[i]);
     for (hipEvent_t e : r->events) if (e) (void)hipEventDestroy(e);
     if (r->start) (void)hipEventDestroy(r->start);
     delete r;
@@ -65,7 +91,15 @@ extern "C" int sempyr_replay_destroy(sempyr_replay* r)
 
 extern "C" int sempyr_replay_create(void* hip_graph, int max_streams, sempyr_replay** out, int32_t* stats)
 {
-    if (!hip_graph || !out) { sempyr_set_error("replay_create: null argument"); return SEMPYR_ERR_INVALID; }
+    return sempyr_replay_create_on(hip_graph, max_streams, nullptr, 0, out, stats);
+}
+
+extern "C" int sempyr_replay_create_on(void* hip_graph, int max_streams, void* const* side_streams, int n_side_streams,
+                                       sempyr_replay** out, int32_t* stats)
+{
+    if (!hip_graph || !out || n_side_streams < 0 || (n_side_streams > 0 && !side_streams)) {
+        sempyr_set_error("replay_create: null argument"); return SEMPYR_ERR_INVALID;
+    }
     if (max_streams < 1) max_streams = 1;
     if (max_streams > 16) max_streams = 16;
     hipGraph_t graph = (hipGraph_t)hip_graph;
@@ -233,8 +267,9 @@ extern "C" int sempyr_replay_create(void* hip_graph, int max_streams, sempyr_rep
     }
     r->streams.assign(tail.size(), nullptr);
     for (size_t st = 1; st < tail.size(); ++st) {
-        hipError_t e = hipStreamCreateWithFlags(&r->streams[st], hipStreamNonBlocking);
-        if (e != hipSuccess) { sempyr_set_error("replay_create: hipStreamCreate: %s", hipGetErrorString(e)); sempyr_replay_destroy(r); return (int)e; }
+        if ((int)st - 1 < n_side_streams) { r->streams[st] = (hipStream_t)side_streams[st - 1]; continue; }
+        const int rc = shared_stream((int)st - 1 - n_side_streams, &r->streams[st]);
+        if (rc != 0) { sempyr_replay_destroy(r); return rc; }
     }
     for (hipEvent_t& ev : r->events) {
         hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);

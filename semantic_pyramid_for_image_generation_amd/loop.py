@@ -3,8 +3,19 @@
 One loop iteration = Python-RNG draws (train type, layer, crop) -> classifier taps -> masks -> critic step
 (`train_discriminator`) -> every `discriminator_steps`-th iteration a generator step (`train_generator`).  Issued from
 Python this is ~500 kernel launches per iteration and the host, not the GPU, sets the pace.
-`TrainLoop` therefore captures the body ONCE per variant into a HIP graph (torch.cuda.CUDAGraph is the plumbing: capture
-stream, private memory pool) and replays it:
+`TrainLoop` therefore captures the body ONCE per variant and replays it -- as TWO graphs, because the body has two halves
+with different dependencies:
+
+  * stage A ("prefetch": both Normalizes, masks, classifier taps, the critic step's detached generator forward and, in an
+    iteration that ends with a generator step, that step's own forward with its autograd graph) depends only on the
+    generator's last update;
+  * stage B (critic step [+ generator step]) depends on stage A and on the previous stage B.
+
+Replayed, stage A of iteration i+1 is launched on the prefetch stream right after stage B of iteration i has been queued on
+the main stream, so it runs UNDER that step's backward pass -- the same overlap the eager three-stream schedule has, without
+the host in the way (one captured graph per iteration cannot do this: round 2 measured it slower than eager).  Two stage-A
+graphs in flight need two sets of static inputs / outputs: every variant is captured twice ("parity" = iteration & 1), and
+stage A of iteration i+2 waits for the event behind stage B of iteration i, whose buffers it overwrites.
 
   * the variants are keyed by what changes the kernel sequence: whether the iteration ends with a generator step, the
     train type and the selected layer L (the number of feature-loss terms; which masks are all-zero);
@@ -33,33 +44,71 @@ _USE_GRAPHS_ENV = os.environ.get("SEMPYR_GRAPHS", "1") != "0"
 # who replays a captured body: "own" = sempyr_replay_launch (plain stream launches from native code, branches on several
 # streams); "hip" = hipGraphLaunch through torch (kept for A/B: in ROCm 7.2 it runs the branches one after the other)
 _GRAPH_EXEC_ENV = os.environ.get("SEMPYR_GRAPH_EXEC", "own")
-_REPLAY_STREAMS = int(os.environ.get("SEMPYR_REPLAY_STREAMS", "4"))
+_REPLAY_STREAMS = int(os.environ.get("SEMPYR_REPLAY_STREAMS", "3"))
+
+
+class _Slot:
+    """The static inputs of one pipeline parity (what the captured stages read) and the event behind the last stage B that
+    read them and stage A's outputs."""
+
+    def __init__(self, B, image_size, shapes, dev):
+        self.images = torch.zeros(B, 3, image_size, image_size, device=dev)
+        self.z_d = torch.zeros(B, 128, 1, 1, device=dev)
+        self.alpha = torch.zeros(B, 1, 1, 1, device=dev)
+        self.z_g = torch.zeros(B, 128, 1, 1, device=dev)
+        self.z2 = torch.zeros(B, 128, 1, 1, device=dev)
+        self.spec_dev = torch.zeros(36, dtype=torch.int32, device=dev)
+        # only the masks that anything reads are kept as tensors: levels 1..4 (generator.py:126-129, train_model.py:212-222)
+        self.masks = [None] + [torch.zeros(shapes[i], device=dev) for i in range(1, 5)] + [None]
+        self.b_done = None
+
+    def tensors(self):
+        return (self.images, self.z_d, self.alpha, self.z_g, self.z2)
 
 
 class _Captured:
-    """One captured variant of the body: the torch graph object (owner of the private memory pool and of the hipGraph_t),
-    the body's outputs (tensors in that pool) and, for the native executor, the replay plan."""
+    """One captured variant of the body at one parity: the two torch graph objects (owners of the hipGraph_t; the memory
+    lives in the loop's per-stage, per-parity pools), the body's outputs and, for the native executor, the replay plans."""
 
-    def __init__(self, graph, out, executor):
-        self.graph, self.out, self.plan, self.stats = graph, out, None, None
+    def __init__(self, graph_a, graph_b, out, executor, side_streams=()):
+        self.graph_a, self.graph_b, self.out = graph_a, graph_b, out
+        self.plan_a = self.plan_b = self.stats = None
         if executor == "own":
-            plan = ctypes.c_void_p()
-            stats = (ctypes.c_int32 * 8)()
-            _lib.check(_lib.lib.sempyr_replay_create(graph.raw_cuda_graph(), _REPLAY_STREAMS, ctypes.byref(plan), stats),
-                       "sempyr_replay_create")
-            self.plan, self.stats = plan, list(stats)
+            stats_a, stats_b = (ctypes.c_int32 * 8)(), (ctypes.c_int32 * 8)()
+            pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+            # stage A is one chain: it runs on the prefetch stream alone; stage B forks onto the shared side streams
+            _lib.check(_lib.lib.sempyr_replay_create(graph_a.raw_cuda_graph(), 1, ctypes.byref(pa), stats_a), "sempyr_replay_create")
+            self.plan_a = pa
+            # ... starting with the streams the eager schedule uses for its branches: the same stream -> hardware-queue
+            # mapping as eager execution (streams created per plan landed two busy streams on one queue: measured)
+            side = (ctypes.c_void_p * max(len(side_streams), 1))(*side_streams)
+            _lib.check(_lib.lib.sempyr_replay_create_on(graph_b.raw_cuda_graph(), _REPLAY_STREAMS, side, len(side_streams),
+                                                        ctypes.byref(pb), stats_b), "sempyr_replay_create_on")
+            self.plan_b = pb
+            self.stats_a, self.stats = list(stats_a), list(stats_b)
 
-    def replay(self, device):
-        if self.plan is not None:
-            _lib.check(_lib.lib.sempyr_replay_launch(self.plan, torch._C._cuda_getCurrentRawStream(device.index)),
-                       "sempyr_replay_launch")
+    def _replay(self, plan, graph, raw_stream):
+        if plan is not None:
+            _lib.check(_lib.lib.sempyr_replay_launch(plan, raw_stream), "sempyr_replay_launch")
         else:
-            self.graph.replay()
+            graph.replay()          # hipGraphLaunch on the current stream
+
+    def replay_a(self, raw_stream):
+        self._replay(self.plan_a, self.graph_a, raw_stream)
+
+    def replay_b(self, raw_stream):
+        self._replay(self.plan_b, self.graph_b, raw_stream)
 
     def __del__(self):
-        if self.plan is not None:
-            _lib.lib.sempyr_replay_destroy(self.plan)
-            self.plan = None
+        plans = [p for p in (self.plan_a, self.plan_b) if p is not None]
+        self.plan_a = self.plan_b = None
+        if plans:
+            try:
+                torch.cuda.synchronize()          # a replay may still be running on the plan's streams / events
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+            for p in plans:
+                _lib.lib.sempyr_replay_destroy(p)
 
 
 class TrainLoop:
@@ -89,16 +138,16 @@ class TrainLoop:
         self.crit_dd = criterion_diversity_d or tm.L1Loss()
         self.iterations = 0
         dev, B = self.device, batch_size
-        # device-resident inputs of the body
-        self.images = torch.zeros(B, 3, image_size, image_size, device=dev)
-        self.z_d = torch.zeros(B, 128, 1, 1, device=dev)
-        self.alpha = torch.zeros(B, 1, 1, 1, device=dev)
-        self.z_g = torch.zeros(B, 128, 1, 1, device=dev)
-        self.z2 = torch.zeros(B, 128, 1, 1, device=dev)
-        self.spec_dev = torch.zeros(36, dtype=torch.int32, device=dev)
-        self.tap_shapes = None          # known after the first classifier pass
-        self.masks = None
-        self.graphs = {}
+        self.image_size = image_size
+        s_ = image_size
+        self.tap_shapes = [(B, 64, s_ // 2, s_ // 2), (B, 64, s_ // 4, s_ // 4), (B, 128, s_ // 8, s_ // 8), (B, 256, s_ // 16, s_ // 16),
+                           (B, 512, s_ // 32, s_ // 32), (B, 512, 1, 1)]
+        # device-resident inputs of the captured stages, one set per pipeline parity (created with the first capture)
+        self.slots = None
+        self.graphs = {}                # (variant key, parity) -> _Captured
+        self._pools = {}
+        self._cap_stream = None
+        self._parity = 0
         self.seen = set()
         self.features_to_train = None
         self.train_type = None
@@ -110,14 +159,12 @@ class TrainLoop:
 
     # ------------------------------------------------------------------------------------------------
     def _tap_shapes(self):
-        if self.tap_shapes is None:
-            s = self.images.shape[2]
-            B = self.B
-            self.tap_shapes = [(B, 64, s // 2, s // 2), (B, 64, s // 4, s // 4), (B, 128, s // 8, s // 8), (B, 256, s // 16, s // 16),
-                               (B, 512, s // 32, s // 32), (B, 512, 1, 1)]
-            # only the masks that anything reads are kept as tensors: levels 1..4 (generator.py:126-129, train_model.py:212-222)
-            self.masks = [None] + [torch.zeros(self.tap_shapes[i], device=self.device) for i in range(1, 5)] + [None]
         return self.tap_shapes
+
+    def _slots(self):
+        if self.slots is None:
+            self.slots = [_Slot(self.B, self.image_size, self.tap_shapes, self.device) for _ in range(2)]
+        return self.slots
 
     def draw(self):
         """The host-side draws of one iteration, in the reference's order (train_model.py:301 train type, :327 layer, :201
@@ -133,20 +180,21 @@ class TrainLoop:
         do_g = (it % self.d_steps == 1)          # train_model.py:336 verbatim (never true for discriminator_steps == 1)
         return (do_g, bool(is1), L)
 
-    def _draw_device(self, key, images, static):
+    def _draw_device(self, key, images, slot):
         """The device-side inputs of the body, drawn in the reference's order (train_model.py:128 z on the CPU generator; :53
-        alpha, :90 z, :107 z2 on the device generator).  static: written into the buffers a captured body reads; otherwise
-        fresh tensors (an eagerly issued body overlaps the previous iteration, which may still be reading its own)."""
+        alpha, :90 z, :107 z2 on the device generator), on the current stream.  slot: written into the buffers a captured
+        body reads; None: fresh tensors (an eagerly issued body overlaps the previous iteration, which may still be reading
+        its own).  `images` may still be in host memory: it is uploaded here, on the stream that consumes it."""
         do_g = key[0]
         dev, B = self.device, self.B
         inp = Namespace()
-        if static:
-            if images is not self.images:
-                self.images.copy_(images, non_blocking=True)
-            inp.images, inp.spec_dev, inp.masks = self.images, self.spec_dev, self.masks
-            inp.z_d, inp.alpha, inp.z_g, inp.z2 = self.z_d, self.alpha, self.z_g, self.z2
+        if slot is not None:
+            if images is not slot.images:
+                slot.images.copy_(images, non_blocking=True)
+            inp.images, inp.spec_dev, inp.masks = slot.images, slot.spec_dev, slot.masks
+            inp.z_d, inp.alpha, inp.z_g, inp.z2 = slot.z_d, slot.alpha, slot.z_g, slot.z2
         else:
-            inp.images = images
+            inp.images = images if images.is_cuda else images.to(dev, non_blocking=True)
             inp.spec_dev = torch.empty(36, dtype=torch.int32, device=dev)
             inp.masks = [None] + [torch.empty(self.tap_shapes[i], device=dev) for i in range(1, 5)] + [None]
             inp.z_d = torch.empty(B, 128, 1, 1, device=dev)
@@ -162,83 +210,131 @@ class TrainLoop:
                 torch.randn(inp.z2.shape, out=inp.z2)
         return inp
 
-    def _static_inputs(self):
-        inp = Namespace(images=self.images, spec_dev=self.spec_dev, masks=self.masks, z_d=self.z_d, alpha=self.alpha,
-                        z_g=self.z_g, z2=self.z2)
-        return inp
+    @staticmethod
+    def _slot_inputs(slot):
+        return Namespace(images=slot.images, spec_dev=slot.spec_dev, masks=slot.masks, z_d=slot.z_d, alpha=slot.alpha,
+                         z_g=slot.z_g, z2=slot.z2)
 
-    def _body(self, key, inp=None, images=None):
-        """classifier taps -> masks -> critic step [-> generator step].  `inp`: the device-side inputs (a captured body reads
-        the static ones); None: draw them here, inside the prefetch block, so that they are produced on the stream that
-        consumes them first."""
+    def _stage_a(self, key, inp, with_g_forward):
+        """Both Normalizes, masks, classifier taps, the critic step's detached generator forward and (with_g_forward) the
+        generator step's own forward -- everything of an iteration that does not depend on the previous critic step."""
         do_g, is1, L = key
-        B, dev = self.B, self.device
+        pre = Namespace()
+        pre.images_d = self.normalizer_d(inp.images)
+        ops.build_masks(inp.masks[1:5], inp.spec_dev[6:30])
+        pre.masks = [None] + [tm.tag_mask(inp.masks[i], self.specs[i]) for i in range(1, 5)] + [None]
+        upto = tm.live_taps(pre.masks)          # taps behind it are multiplied by all-zero masks wherever they are used
+        with torch.no_grad():
+            if upto is None:
+                _, pre.features = self.C(self.normalizer_clf(inp.images))
+            else:
+                _, pre.features = self.C(self.normalizer_clf(inp.images), taps_upto=upto) if upto else (None, [None] * 6)
+        pre.fake = tm.fake_for_discriminator(self.G, self.B, pre.features, pre.masks, z=inp.z_d)
+        pre.fake_g = tm.fake_for_generator(self.G, pre.features, pre.masks, inp.z_g) if (do_g and with_g_forward) else None
+        return pre
+
+    def _stage_b(self, key, inp, pre):
+        """critic step [-> generator step] (train_model.py:331-339)"""
+        do_g, is1, L = key
         train_type = 1 if is1 else [2]
-        with tm.prefetch(self.G, dev) as pf:            # (runs in place while a graph is being captured)
-            if inp is None:
-                inp = self._draw_device(key, images, static=False)
-                pf.hand_over(inp.alpha, inp.z_g, inp.z2)
-            images_d = self.normalizer_d(inp.images)
-            ops.build_masks(inp.masks[1:5], inp.spec_dev[6:30])
-            masks = [None] + [tm.tag_mask(inp.masks[i], self.specs[i]) for i in range(1, 5)] + [None]
-            upto = tm.live_taps(masks)          # taps behind it are multiplied by all-zero masks wherever they are used
-            with torch.no_grad():
-                if upto is None:
-                    _, features = self.C(self.normalizer_clf(inp.images))
-                else:
-                    _, features = self.C(self.normalizer_clf(inp.images), taps_upto=upto) if upto else (None, [None] * 6)
-            fake = tm.fake_for_discriminator(self.G, B, features, masks, z=inp.z_d)
-            pf.hand_over(images_d, features, masks[1:5], fake)
-            fake_g = None
-            if do_g and pf.on:
-                fake_g = tm.fake_for_generator(self.G, features, masks, inp.z_g)
-                pf.hand_over(fake_g)
-        d_losses = tm.train_discriminator(self.G, self.D, self.d_loss_fn, self.d_opt, images_d, features, masks,
-                                          alpha=inp.alpha, fake_images=fake)
+        d_losses = tm.train_discriminator(self.G, self.D, self.d_loss_fn, self.d_opt, pre.images_d, pre.features, pre.masks,
+                                          alpha=inp.alpha, fake_images=pre.fake)
         g_losses = None
         if do_g:
-            g_losses = tm.train_generator(self.G, self.D, self.g_loss_fn, self.g_opt, B, features, self.crit_f, L, self.C,
-                                          self.normalizer_clf, self.crit_dn, self.crit_dd, masks, train_type,
-                                          z=inp.z_g, z2=inp.z2, fake_images=fake_g)
-        return {'d': d_losses, 'g': g_losses, 'features': features, 'masks': masks, 'images_d': images_d}
+            g_losses = tm.train_generator(self.G, self.D, self.g_loss_fn, self.g_opt, self.B, pre.features, self.crit_f, L, self.C,
+                                          self.normalizer_clf, self.crit_dn, self.crit_dd, pre.masks, train_type,
+                                          z=inp.z_g, z2=inp.z2, fake_images=pre.fake_g)
+        return {'d': d_losses, 'g': g_losses, 'features': pre.features, 'masks': pre.masks, 'images_d': pre.images_d}
 
-    def _capture(self, key):
-        torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph(keep_graph=(self.executor == "own"))
+    def _body(self, key, inp=None, images=None):
+        """One eagerly issued iteration: stage A inside the prefetch block (its own stream, see train_model.prefetch), then
+        stage B.  `inp`: the device-side inputs; None: draw them here, inside the prefetch block, so that they are produced on
+        the stream that consumes them first."""
+        with tm.prefetch(self.G, self.device) as pf:
+            if inp is None:
+                inp = self._draw_device(key, images, None)
+                pf.hand_over(inp.alpha, inp.z_g, inp.z2)
+            pre = self._stage_a(key, inp, pf.on)
+            pf.hand_over(pre.images_d, pre.features, pre.masks[1:5], pre.fake, pre.fake_g)
+        return self._stage_b(key, inp, pre)
+
+    def _capture(self, key, parity):
+        """Record the two stages of variant `key` reading / writing the buffers of `parity`.  Both captures run on one capture
+        stream (stage B's backward pass replays nodes of the autograd graph that stage A built: the engine issues them on the
+        stream of their forward) and in different capture epochs (stage B must not wait on events recorded inside stage A's
+        capture; stage A is complete when stage B starts, by the event the launcher records between them)."""
+        dev = self.device
+        torch.cuda.synchronize(dev)
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=dev)
+        for st in ('A', 'B'):
+            if (st, parity) not in self._pools:
+                self._pools[(st, parity)] = torch.cuda.graph_pool_handle()
+        keep = (self.executor == "own")
+        ga, gb = torch.cuda.CUDAGraph(keep_graph=keep), torch.cuda.CUDAGraph(keep_graph=keep)
+        inp = self._slot_inputs(self._slots()[parity])
         with ops.capture_epoch():
-            with torch.cuda.graph(graph):
-                out = self._body(key, self._static_inputs())
-        torch.cuda.synchronize(self.device)
-        self.graphs[key] = _Captured(graph, out, self.executor)
+            with torch.cuda.graph(ga, pool=self._pools[('A', parity)], stream=self._cap_stream):
+                pre = self._stage_a(key, inp, True)
+        with ops.capture_epoch():
+            with torch.cuda.graph(gb, pool=self._pools[('B', parity)], stream=self._cap_stream):
+                out = self._stage_b(key, inp, pre)
+        del pre
+        torch.cuda.synchronize(dev)
+        side = [ops._side_stream(dev).cuda_stream, ops._side_stream2(dev).cuda_stream]
+        self.graphs[(key, parity)] = _Captured(ga, gb, out, self.executor, side)
 
     def _advance_optimizers(self, do_g):
         self.d_opt.advance()
         if do_g:
             self.g_opt.advance()
 
+    def _replay(self, cap, key, images, parity):
+        """Launch the two captured stages of one iteration: stage A on the prefetch stream (behind the generator's last update
+        and behind the stage B that last read this parity's buffers), stage B on the current stream behind stage A."""
+        dev = self.device
+        slot = self.slots[parity]
+        main = ops._current_stream_obj(dev)
+        pre = ops.prefetch_stream(dev)
+        torch.cuda.set_stream(pre)
+        try:
+            if slot.b_done is not None:
+                pre.wait_event(slot.b_done)
+            tm._wait_for_generator_update(self.G, dev)
+            self._draw_device(key, images, slot)
+            cap.replay_a(pre.cuda_stream)
+            a_done = torch.cuda.Event()
+            a_done.record(pre)
+        finally:
+            torch.cuda.set_stream(main)
+        main.wait_event(a_done)
+        self._advance_optimizers(key[0])
+        cap.replay_b(main.cuda_stream)
+        slot.b_done = torch.cuda.Event()
+        slot.b_done.record(main)
+        if key[0]:
+            # (every generator forward of a replayed iteration runs on the prefetch stream or, inside the generator step,
+            # in front of this event: an eager iteration that follows is ordered behind all of them)
+            tm.mark_generator_updated(self.G, dev)
+        return cap.out
+
     def iteration(self, images, log=False):
-        """One loop iteration on `images` ((B,3,H,W) in [0,1], already on the device).  `log`: also keep the loss scalars for
-        pop_logged().  Returns {'d': {...}, 'g': {...} | None, 'features', 'masks', 'images_d'}; the tensors of a replayed
-        body are overwritten by the next iteration of the same variant."""
+        """One loop iteration on `images` ((B,3,H,W) in [0,1]; on the device and complete, or in (pinned) host memory -- it is
+        then uploaded on the prefetch stream).  `log`: also keep the loss scalars for pop_logged().  Returns {'d': {...},
+        'g': {...} | None, 'features', 'masks', 'images_d'}; the tensors of a replayed body are overwritten by the replayed
+        iteration after the next."""
         key = self.draw()
         out = None
         if self.use_graphs:
-            cap = self.graphs.get(key)
-            if cap is None and key in self.seen:
-                self._draw_device(key, images, static=True)
-                self._capture(key)
-                cap = self.graphs[key]
-            elif cap is not None:
-                self._draw_device(key, images, static=True)
+            self._parity ^= 1
+            parity = self._parity
+            cap = self.graphs.get((key, parity))
+            if cap is None and (key, parity) in self.seen:
+                self._capture(key, parity)
+                cap = self.graphs[(key, parity)]
             if cap is not None:
-                self._advance_optimizers(key[0])
-                cap.replay(self.device)
-                # every body touches the generator (its train-mode forwards update the BatchNorm running statistics): an
-                # eagerly issued body that follows must not start its generator forward on the prefetch stream before this
-                # one is done, whether or not it ended with a generator step
-                tm.mark_generator_updated(self.G, self.device)
-                out = cap.out
-            self.seen.add(key)
+                out = self._replay(cap, key, images, parity)
+            self.seen.add((key, parity))
         if out is None:
             out = self._body(key, None, images)
         self.last = out
@@ -279,9 +375,9 @@ class TrainLoop:
         return out
 
     def prepare(self, keys=None):
-        """Warm and capture every variant ahead of time (first use of a shape cannot be captured) on throw-away inputs, then
-        put parameters, buffers and optimizer state back bit-exactly: training is unaffected, and no iteration of the real
-        loop pays for a capture.  Python's and torch's RNG streams are not touched."""
+        """Warm and capture every variant (at both parities) ahead of time -- first use of a shape cannot be captured -- on
+        throw-away inputs, then put parameters, buffers and optimizer state back bit-exactly: training is unaffected, and
+        no iteration of the real loop pays for a capture.  Python's and torch's RNG streams are not touched."""
         if not self.use_graphs:
             return
         if keys is None:
@@ -289,11 +385,12 @@ class TrainLoop:
             keys = [(g, False, L) for g in (False, True) for L in layers]
         shapes = self._tap_shapes()
         gen = torch.Generator(device='cpu').manual_seed(987)
-        saved_inputs = [t.clone() for t in (self.images, self.z_d, self.alpha, self.z_g, self.z2)]
-        self.images.copy_(torch.rand(self.images.shape, generator=gen))
-        for t in (self.z_d, self.z_g, self.z2):
-            t.copy_(torch.randn(t.shape, generator=gen))
-        self.alpha.copy_(torch.rand(self.alpha.shape, generator=gen))
+        slots = self._slots()
+        for slot in slots:
+            slot.images.copy_(torch.rand(slot.images.shape, generator=gen))
+            for t in (slot.z_d, slot.z_g, slot.z2):
+                t.copy_(torch.randn(t.shape, generator=gen))
+            slot.alpha.copy_(torch.rand(slot.alpha.shape, generator=gen))
         with torch.no_grad():
             snap = [(t, t.detach().clone()) for t in self._state_tensors()]
         opt_snap = []
@@ -301,18 +398,21 @@ class TrainLoop:
             had = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state[p].items()}
                    for g in opt.param_groups for p in g['params'] if len(opt.state[p]) != 0}
             opt_snap.append((opt, had))
+        warmed = set()
         for key in keys:
-            if key in self.graphs:
-                continue
             do_g, is1, L = key
-            self.specs = tm.mask_specs(shapes, is1, L, None if is1 else (30, 30))
-            ops.store_words(self.spec_dev, tm.spec_words(self.specs))
-            torch.cuda.synchronize(self.device)      # (the eager body starts on the prefetch stream, which does not follow this one)
-            if key not in self.seen:
-                self._body(key, self._static_inputs())
-                torch.cuda.synchronize(self.device)
-                self.seen.add(key)
-            self._capture(key)
+            for parity in (0, 1):
+                if (key, parity) in self.graphs:
+                    continue
+                self.specs = tm.mask_specs(shapes, is1, L, None if is1 else (30, 30))
+                ops.store_words(slots[parity].spec_dev, tm.spec_words(self.specs))
+                torch.cuda.synchronize(self.device)      # (the eager body starts on the prefetch stream, which does not follow this one)
+                if key not in warmed and not any((key, q) in self.seen for q in (0, 1)):
+                    self._body(key, self._slot_inputs(slots[parity]))
+                    torch.cuda.synchronize(self.device)
+                warmed.add(key)
+                self.seen.add((key, parity))
+                self._capture(key, parity)
         with torch.no_grad():
             for t, v in snap:
                 t.copy_(v)
@@ -334,8 +434,6 @@ class TrainLoop:
                 for gi, g in enumerate(opt.param_groups):
                     torch.autograd.graph.increment_version(list(g['params']))
                     ops.repack_cached(g['params'], None)
-            for t, v in zip((self.images, self.z_d, self.alpha, self.z_g, self.z2), saved_inputs):
-                t.copy_(v)
         for m in (self.G, self.D):
             for p in m.parameters():
                 p.grad = None

@@ -670,6 +670,7 @@ def _main():
                      discriminator_steps=args.discriminator_steps, train1_prob=args.train1_prob, fixed_layer=args.fixed_layer,
                      normalizer_clf=normalizer_clf, normalizer_discriminator=normalizer_discriminator,
                      use_graphs=False if world > 1 else None)       # (a collective inside a captured body is not rehearsed)
+    loop.prepare()          # warm + capture every body variant now: the loop never mixes eager and replayed iterations
 
     starting_time = time.time()
     iterations = 0
@@ -696,12 +697,13 @@ def _main():
                 print('epoch:', epoch, ', iter', iterations, 'start, time =', time.time() - starting_time, 'seconds')
                 starting_time = time.time()
             images, _ = data
-            images = images.to(device, non_blocking=True)
+            # (the pinned host batch goes to the loop as it is: the upload is issued on the loop's prefetch stream, in front of
+            # the work that reads it, instead of on this stream behind the previous iteration's backward pass)
             out = loop.iteration(images, log=writer is not None)
             if first_iter and rank == 0:
                 first_iter = False
                 with torch.no_grad():       # every tap of the first batch (the loop only computes the taps an iteration reads)
-                    _, features = classifier(normalizer_clf(images))
+                    _, features = classifier(normalizer_clf(images.to(device)))
                 images_discriminator = out['images_d']
                 fixed_features = [torch.clone(f) for f in features]
                 fixed_masks = [torch.ones(f.shape, device=device) for f in features]
