@@ -154,7 +154,7 @@ def main():
     ap.add_argument('--profile-pass', action='store_true',
                     help='run ONLY the single-stream instrumented pass of --steps cycles, bracketed by sempyr_marker_kernel launches '
                          '(for rocprofv3 --kernel-trace; SEMPYR_PROFILE_DUMP=<csv> keeps the per-launch shapes, see tools/roofline_table.py)')
-    ap.add_argument('--loop-mode', default=os.environ.get('SEMPYR_LOOP_MODE', 'eager'), choices=['eager', 'replay', 'hipgraph'],
+    ap.add_argument('--loop-mode', default=os.environ.get('SEMPYR_LOOP_MODE', 'replay'), choices=['eager', 'replay', 'hipgraph'],
                     help='eager: the body is issued from Python on four streams; replay: captured once per variant and re-issued by '
                          'sempyr_replay_launch; hipgraph: captured and replayed by hipGraphLaunch')
     a = ap.parse_args()

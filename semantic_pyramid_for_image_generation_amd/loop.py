@@ -276,9 +276,19 @@ class TrainLoop:
         with ops.capture_epoch():
             with torch.cuda.graph(ga, pool=self._pools[('A', parity)], stream=self._cap_stream):
                 pre = self._stage_a(key, inp, True)
-        with ops.capture_epoch():
-            with torch.cuda.graph(gb, pool=self._pools[('B', parity)], stream=self._cap_stream):
-                out = self._stage_b(key, inp, pre)
+        # hipGraphLaunch (kept for A/B only) mis-orders the generator step's forked critic branch when the step's own
+        # forward lives in another graph: the branch reads the critic's weights of BEFORE the critic step that the same graph
+        # contains (measured on ROCm 7.2: g_loss off by one Adam step; the native executor replays the very same DAG
+        # bit-exactly).  For that executor the generator step is recorded unforked.
+        saved_fork = ops.TWO_STREAM_GENERATOR
+        if self.executor == "hip":
+            ops.TWO_STREAM_GENERATOR = False
+        try:
+            with ops.capture_epoch():
+                with torch.cuda.graph(gb, pool=self._pools[('B', parity)], stream=self._cap_stream):
+                    out = self._stage_b(key, inp, pre)
+        finally:
+            ops.TWO_STREAM_GENERATOR = saved_fork
         del pre
         torch.cuda.synchronize(dev)
         side = [ops._side_stream(dev).cuda_stream, ops._side_stream2(dev).cuda_stream]
