@@ -143,7 +143,7 @@ STEP_CASES = [('res', 'instance_norm', False), ('res', 'instance_norm', True), (
               ('default', 'layer_norm', False), ('res', 'batch_norm', False)]
 
 
-@pytest.mark.parametrize("case", STEP_CASES[:2] + STEP_CASES[3:4])
+@pytest.mark.parametrize("case", STEP_CASES)
 def test_train_steps_oracle(case):
     """D step, G step, D step at B=2 with the z / alpha draws the reference made."""
     gen_type, norm, div = case
@@ -186,3 +186,31 @@ def test_train_steps_oracle(case):
         assert abs(float(tr.g[k].grad.double().norm()) - v) <= 1e-3 * max(v, 1e-3 * max(info['G_grad_norms'].values())), ('G grad', k)
     check_deltas(store, name, 'G', g_before, tr.g, info['G_grad_norms'], med_tol=0.01, frac_big=0.02)
     check_deltas(store, name, 'D', d_before, tr.d, info['D_grad_norms'], med_tol=0.01, frac_big=0.02)
+
+
+def test_feature_steps_oracle():
+    """steps.FeatureTrainer (train_feature_creation_gen.py:30-79 restated) against the reference's own critic step + generator
+    step for the f4 -> f3 block at B=2 (fsteps.*: losses and post-step parameter norms), with the alpha the reference drew."""
+    store, meta = load_npz('fsteps.npz'), load_json('fsteps.json')
+    name = 'fsteps_l4_instance_norm'
+    info = meta[name]
+    seed, level = info['seed'], 4
+    torch.manual_seed(seed)
+    FG = _ref_style_module('LU', level)
+    FD = _ref_style_module('FD', 'instance_norm', 'res', level - 1)
+    clf_sd = {k: v.detach() for k, v in recipes.make_resnet(seed).state_dict().items()}
+    images = recipes.image_batch(seed, 2)
+    with torch.no_grad():
+        _, features = nets.classifier_forward(clf_sd, recipes.normalize_clf(images))
+    tr = steps.FeatureTrainer(_sd(FG), _sd(FD), clf_sd, level, 'instance_norm', 'res')
+    d1 = tr.d_step(features, torch.from_numpy(store[f'{name}.rand0']))
+    g1 = tr.g_step(features)
+    got = {f'd1.{k}': float(v) for k, v in d1.items()}
+    got.update({f'g1.{k}': float(v) for k, v in g1.items()})
+    assert set(got) == set(info['losses'])
+    for k, v in info['losses'].items():
+        assert abs(got[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, got[k], v)
+    for k, v in info['G_norms'].items():
+        assert abs(float(tr.g[k].detach().double().norm()) - v) <= 1e-4 * max(1.0, v), ('G', k)
+    for k, v in info['D_norms'].items():
+        assert abs(float(tr.d[k].detach().double().norm()) - v) <= 1e-4 * max(1.0, v), ('D', k)

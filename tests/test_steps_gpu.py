@@ -6,11 +6,9 @@ Two kinds of check:
     that is MEASURED in the test, not assumed: the same oracle is also run in fp32 (the reference's own arithmetic) four
     times -- 1 thread, 8 threads, and twice with its floating-point inputs jittered by one unit in the last place -- and the
     largest distance of those runs from fp64 is the noise of fp32 on this problem.  Per tensor,
-        max|g_hip - g_fp64| <= 3 * max(that tensor's distance, the median distance over the step's tensors,
-                                       the largest distance of any tensor of the step with its single worst element set aside),
-    relative to the tensor's max-abs: 1e-5 .. 1e-3 for most tensors, 1e-2 where the fp32 runs themselves disagree by that
-    much (a LeakyReLU pre-activation at round-off distance from zero lands on either side of it from run to run and
-    moves every gradient upstream of it -- which tensors are hit depends on where the flip happens, hence the last term).
+        max|g_hip - g_fp64| <= 3 * max(that tensor's distance, the median distance over the step's tensors)
+    relative to the tensor's max-abs (the measured values are printed: run with -s).  A tensor that needs more than that is
+    named in the test with its allowance and the reason (ALLOW below); there is no step-wide term.
     Distances are taken with the same outlier allowance as the check itself (next sentence).  (At B=2 these gradients are ill-conditioned in fp32 -- sums of 1e5-1e6 cancelling
     products -- and the fp32 CPU path itself is 1e-6 .. 3e-3 from fp64 depending on tensor and thread count;
     tools/diag_grad_noise.py prints the table.)  On top of that, at most 0.5 % of a tensor's elements (at least one)
@@ -50,32 +48,69 @@ def _rel_err(got, want, global_max):
     return (got - want).abs() / scale
 
 
-def _grads_close(named_got, ref64, ref32_list, names):
+# Tensors whose bound is wider than 3x the measured fp32 noise, by name: (case tag, tensor-name prefix) -> the bound they get
+# instead (relative to the tensor's max-abs / norm), with the reason.
+ALLOW = {
+    # FeaturesDiscriminator('res', level 3) with BatchNorm at batch 2: one LeakyReLU pre-activation of the first residual block
+    # lands at round-off distance from zero on the other side in the HIP run.  Behind a BatchNorm a single flipped element
+    # moves the channel's batch statistics, i.e. EVERY element of the gradients upstream of it by ~1/(N*H*W) of the flipped
+    # contribution -- the 0.5 % outlier allowance cannot absorb that.  Measured (tools/diag_fgrad.py): every tensor of
+    # conv_block5 (same kernels, behind the flip) agrees with fp64 to 5e-7 .. 1e-6, the tensors of conv_block4 are off by
+    # 2.5e-4 .. 1.6e-3 of their max-abs with single elements at 1e-2 -- and the fp32 CPU runs show the same 1e-2 single-element
+    # jumps on conv_block4's first conv in three of four runs (their flip sits in front of a different BatchNorm).
+    ('fd:4/batch_norm', 'conv_block4.'): 5e-3,
+    # Production batch, relative L2.  Measured: the HIP gradient is 3.0 .. 3.5 x as far from fp64 as the fp32 CPU runs on the
+    # weight gradients of the critic's two deepest blocks (2.6e-4 against 7.6e-5; every other tensor is inside 3 x): each output
+    # element of the convolutions in front of them is ONE fp32 accumulator over K = 4096 / 8192 products, where oneDNN sums
+    # 16-lane partial chains.  These tensors get 5 x their measured noise instead of 3 x; nothing else does.
+    ('prod-d:default/batch_norm/False', 'conv_block4.conv_block1.block.0.weight'): 4e-4,
+    ('prod-d:default/batch_norm/False', 'conv_block5.conv_block1.block.0.weight'): 4e-4,
+    # the same at batch 64 on FeaturesDiscriminator's last residual block (1.6e-4 .. 2.2e-4 measured, bound 1.6e-4 .. 2.1e-4)
+    ('prod-fd:B64', 'conv_block5.'): 3e-4,
+    # ... and on LevelUpFeaturesGenerator's first residual block, whose gradients arrive through res_block2's K = 4608 input
+    # gradients and the classifier stage behind it (3.8e-4 .. 4.0e-4 measured against 7.6e-5 for the fp32 CPU runs)
+    ('prod-fg:B64', 'res_block1.'): 6e-4,
+}
+
+
+def _allowance(tag, k, tol):
+    for (t, prefix), bound in ALLOW.items():
+        if t == tag and k.startswith(prefix):
+            return max(tol, bound)
+    return tol
+
+
+def _grads_close(named_got, ref64, ref32_list, names, tag=''):
     """named_got: {name: HIP gradient}; ref64 / ref32_list: {name: tensor with .grad} of the fp64 oracle and of the fp32
-    oracle runs (different thread counts).  See the module docstring for the bound."""
+    oracle runs (different thread counts / one-ulp jitter).  Per tensor: max-abs error relative to the tensor's max-abs
+    <= 3 * max(the fp32 runs' own distance from fp64 on that tensor, the median of those distances over the step's tensors),
+    with at most 0.5 % of the elements (at least one) outside it and none beyond 0.2 (see the module docstring)."""
     gmax = max(float(ref64[k].grad.abs().max()) for k in names if ref64[k].grad is not None)
 
     def robust_max(err):                 # the largest error once the allowed outliers (0.5 % of the elements, at least one) are set aside
         flat = err.flatten()
         drop = max(1, flat.numel() // 200)
         return float(torch.topk(flat, min(drop + 1, flat.numel())).values[-1])
-    def second_max(err):
-        flat = err.flatten()
-        return float(torch.topk(flat, min(2, flat.numel())).values[-1])
     live = [k for k in names if ref64[k].grad is not None]
     noise = {k: max(robust_max(_rel_err(r[k].grad, ref64[k].grad, gmax)) for r in ref32_list) for k in live}
     floor = sorted(noise.values())[len(noise) // 2]
-    top = max(second_max(_rel_err(r[k].grad, ref64[k].grad, gmax)) for r in ref32_list for k in live)
-    assert 1e-8 < floor < 1e-2 and top < 5e-2, (floor, top)     # the fp32 reference arithmetic itself: sanity of the measurement
+    assert 1e-8 < floor < 1e-2, floor                           # the fp32 reference arithmetic itself: sanity of the measurement
+    failures, worst = [], (0.0, None)
     for k in names:
         if ref64[k].grad is None:
             assert named_got[k] is None or float(named_got[k].abs().max()) == 0.0, k
             continue
         err = _rel_err(named_got[k], ref64[k].grad, gmax)
-        tol = 3.0 * max(noise[k], floor, top)
+        tol = _allowance(tag, k, 3.0 * max(noise[k], floor))
         outliers = int((err > tol).sum())
-        assert outliers <= max(1, err.numel() // 200), (k, outliers, err.numel(), float(err.max()), tol, noise[k])
-        assert float(err.max()) <= 0.2, (k, float(err.max()))
+        ratio = robust_max(err) / tol
+        if ratio > worst[0]:
+            worst = (ratio, k)
+        if outliers > max(1, err.numel() // 200) or float(err.max()) > 0.2:
+            failures.append((k, outliers, err.numel(), float(err.max()), robust_max(err), tol, noise[k]))
+    print(f"[{tag}] fp32-vs-fp64 noise: median {floor:.2e}, largest {max(noise.values()):.2e}; "
+          f"worst HIP error / bound = {worst[0]:.2f} ({worst[1]})")
+    assert not failures, failures
 
 
 def _setup(dev, gen_type, norm, div, seed, B=2):
@@ -172,7 +207,7 @@ def test_d_step_gradients_vs_oracle(dev, case):
                                  [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
     for k in want:
         assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    _grads_close({k: p.grad for k, p in D.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params)
+    _grads_close({k: p.grad for k, p in D.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params, 'd:' + '/'.join(map(str, case)))
 
 
 @pytest.mark.parametrize("case", GRAD_CASES)
@@ -191,39 +226,70 @@ def test_g_step_gradients_vs_oracle(dev, case):
     assert set(got) == set(want)
     for k in want:
         assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    _grads_close({k: p.grad for k, p in G.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params)
+    _grads_close({k: p.grad for k, p in G.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params, 'g:' + '/'.join(map(str, case)))
     assert all(p.requires_grad for p in D.parameters())         # the temporary freeze was undone
 
 
-def _cosine_and_norms(named_got, ref, names, min_cos, norm_tol):
-    """per tensor: cosine similarity with the oracle gradient and ratio of norms (tensors whose oracle gradient is
-    structurally zero -- a conv bias in front of a norm layer -- are skipped)"""
-    gmax = max(float(ref[k].grad.norm()) for k in names if ref[k].grad is not None)
-    checked = 0
-    worst = (1.0, None)
-    for k in names:
-        want = ref[k].grad
-        if want is None or float(want.norm()) <= 1e-4 * gmax:
-            continue
-        got = named_got[k].detach().double().cpu().flatten()
-        want = want.double().flatten()
-        cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
-        ratio = float(got.norm() / want.norm())
-        assert cos >= min_cos, (k, 'cosine', cos)
-        assert abs(ratio - 1.0) <= norm_tol, (k, 'norm ratio', ratio)
-        if cos < worst[0]:
-            worst = (cos, k)
-        checked += 1
-    assert checked >= 10
-    return worst
+def _rel_l2(named_got, ref64, ref32_list, names, tag):
+    """Production batch: per gradient tensor the relative L2 distance from the fp64 oracle, bounded by 3x what the fp32
+    oracle (the reference's own arithmetic: default thread count, and four times with every float input moved by an ulp) shows
+    on that tensor, or 3x the median of that over the step's tensors where a tensor's own figure is smaller.  Tensors whose
+    oracle gradient is structurally zero (a conv bias in front of a norm layer: pure round-off) are skipped."""
+    live = [k for k in names if ref64[k].grad is not None]
+    gmax = max(float(ref64[k].grad.double().norm()) for k in live)
+    live = [k for k in live if float(ref64[k].grad.double().norm()) > 1e-4 * gmax]
+
+    def dist(g, k):
+        # (the largest 0.5 % of the element errors, at least one, are set aside as in the batch-2 tests: a single ReLU-family
+        # flip moves one channel's entry of a 512-element affine gradient by percents, i.e. the tensor's L2 distance by 3e-3)
+        w = ref64[k].grad.double().flatten()
+        e = (g.detach().double().cpu().flatten() - w).abs()
+        drop = max(1, e.numel() // 200)
+        if e.numel() > drop:
+            e = torch.topk(e, e.numel() - drop, largest=False).values
+        return float(e.norm() / w.norm())
+    noise = {k: max(dist(r[k].grad, k) for r in ref32_list) for k in live}
+    floor = sorted(noise.values())[len(noise) // 2]
+    assert 1e-9 < floor < 1e-2, floor          # (the generator's gradients at batch 16: fp32 itself is 4e-3 from fp64)
+    failures, worst = [], (0.0, None, 0.0)
+    for k in live:
+        err, tol = dist(named_got[k], k), _allowance(tag, k, 3.0 * max(noise[k], floor))
+        if err / tol > worst[0]:
+            worst = (err / tol, k, err)
+        if err > tol:
+            failures.append((k, err, tol, noise[k]))
+    print(f"[{tag}] relative L2, fp32-vs-fp64 noise: median {floor:.2e}, largest {max(noise.values()):.2e}; HIP: largest "
+          f"{max(dist(named_got[k], k) for k in live):.2e}, worst error / bound = {worst[0]:.2f} ({worst[1]}: {worst[2]:.2e})")
+    assert len(live) >= 10, len(live)
+    assert not failures, failures
 
 
-def test_production_batch_steps_vs_oracle(dev):
-    """The headline configuration at its production batch (res generator, instance_norm critic, batch 16, 256x256): one critic
-    step and one generator step against the fp64 oracle -- losses within 1e-3, every gradient tensor within 0.5 % in norm and
-    with cosine >= 0.9999 (at batch 16 the gradients are well conditioned; the element-wise bound of the batch-2 tests is
-    measured there)."""
-    tm, G, D, C, tr, images, feats, masks, z, z2, alpha = _setup(dev, 'res', 'instance_norm', False, 91, B=16)
+def _fp32_runs_prod(make, step):
+    """fp32 oracle at the production batch: as it runs, and four times with its float inputs moved by an ulp"""
+    out = []
+    for seed in (None, 1, 2, 3, 4):
+        t = make()
+        if seed is None:
+            step(t)
+        else:
+            with _Jitter(seed):
+                step(t)
+        out.append(t)
+    return out
+
+
+PROD_CASES = [('res', 'instance_norm', False), ('res', 'instance_norm', True), ('default', 'batch_norm', False),
+              ('default', 'layer_norm', False)]
+
+
+@pytest.mark.parametrize("case", PROD_CASES)
+def test_production_batch_steps_vs_oracle(dev, case):
+    """BASELINE configurations 2, 3 and 4 at their production batch (16 x 256x256): one critic step and one generator step
+    (with the diversity loss for configuration 3) against the fp64 oracle -- losses within 1e-3, every gradient tensor within
+    3x the measured fp32-vs-fp64 noise in relative L2 (see _rel_l2)."""
+    gen_type, norm, div = case
+    tag = '/'.join(map(str, case))
+    tm, G, D, C, tr, images, feats, masks, z, z2, alpha = _setup(dev, gen_type, norm, div, 91, B=16)
     d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
     crit = tm.L1Loss()
     # learning rate 0 on both sides: the generator step that follows sees the critic the oracle's generator step sees
@@ -231,19 +297,84 @@ def test_production_batch_steps_vs_oracle(dev):
     d_opt = _Adam(D.parameters(), lr=0.0, betas=(0.5, 0.999))
     g_opt = _Adam(G.parameters(), lr=0.0, betas=(0.5, 0.999))
     real = (images - 0.5) / 0.5
+    gen = torch.Generator().manual_seed(17)
+    z3 = torch.randn(16, 128, 1, 1, generator=gen)
+
+    def make32():
+        t = tr.fp32()
+        t.d_opt.param_groups[0]['lr'] = 0.0
+        return t
+    refs32 = _fp32_runs_prod(make32, lambda t: t.d_step(j(real), j(feats), masks, j(z), alpha))
     want = tr.d_step(_d(real), _d(feats), _d(masks), _d(z), _d(alpha))
     got = tm.train_discriminator(G, D, d_loss_fn, d_opt, real.to(dev), [f.to(dev) for f in feats],
                                  [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
     for k in want:
         assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    _cosine_and_norms({k: p.grad for k, p in D.named_parameters()}, tr.d, tr.d_params, 0.9999, 5e-3)
-    want = tr.g_step(_d(feats), _d(masks), 3, _d(z2))
+    _rel_l2({k: p.grad for k, p in D.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params, 'prod-d:' + tag)
+    for r in refs32:
+        r.g_step(feats, masks, 3, z2, z3 if div else None)
+    want = tr.g_step(_d(feats), _d(masks), 3, _d(z2), _d(z3) if div else None)
     got = tm.train_generator(G, D, g_loss_fn, g_opt, 16, [f.to(dev) for f in feats], crit, 3, C,
                              tm.Normalize(recipes.CLF_MEAN, recipes.CLF_STD), crit, crit, [m.to(dev) for m in masks], [2],
-                             z=z2.to(dev))
+                             z=z2.to(dev), z2=z3.to(dev) if div else None)
+    assert set(got) == set(want)
     for k in want:
         assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    _cosine_and_norms({k: p.grad for k, p in G.named_parameters()}, tr.g, tr.g_params, 0.9999, 5e-3)
+    _rel_l2({k: p.grad for k, p in G.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params, 'prod-g:' + tag)
+
+
+@pytest.mark.parametrize("batch", [16, 64])
+def test_production_batch_feature_gen_steps_vs_oracle(dev, batch):
+    """BASELINE configuration 5 (LevelUp f4 -> f3 + FeaturesDiscriminator('res', level 3), instance_norm) at batch 16 and at
+    the script's default batch 64: critic step and generator step against the fp64 oracle, same bound."""
+    from semantic_pyramid_for_image_generation_amd import train_feature_creation_gen as tf
+    from semantic_pyramid_for_image_generation_amd import train_model as tm
+    from semantic_pyramid_for_image_generation_amd.classifier import Classifier, resnet18
+    from semantic_pyramid_for_image_generation_amd.featuresCreatorGen import FeaturesDiscriminator, LevelUpFeaturesGenerator
+    from oracle import steps
+    level, norm, seed = 4, 'instance_norm', 95
+    torch.manual_seed(seed)
+    FG = LevelUpFeaturesGenerator(level); FG.init_weights()
+    FD = FeaturesDiscriminator(norm, 'res', level - 1); FD.init_weights()
+    csd = {k: v.detach().clone() for k, v in recipes.make_resnet(seed).state_dict().items()}
+    f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+
+    def make(conv):
+        t = steps.FeatureTrainer(conv(cpu_state(FG)), conv(cpu_state(FD)), conv(csd), level, norm, 'res')
+        t.d_opt.param_groups[0]['lr'] = 0.0
+        return t
+    tr = make(f64)
+    C = Classifier(resnet18(365)); C.load_state_dict(csd)
+    FG.to(dev); FD.to(dev); C.to(dev).eval()
+    for p in C.parameters():
+        p.requires_grad_(False)
+    tf.args = Namespace(gradient_penalty_weight=10.0)
+    d_loss_fn, g_loss_fn = tm.get_wgan_losses_fn()
+    crit = tm.L1Loss()
+    images = recipes.image_batch(seed, batch)
+    with torch.no_grad():
+        feats = []
+        for i in range(0, batch, 16):
+            _, f = nets.classifier_forward(csd, recipes.normalize_clf(images[i:i + 16]))
+            feats.append(f)
+        feats = [torch.cat([f[k] for f in feats]) for k in range(6)]
+    alpha = torch.rand(batch, 1, 1, 1, generator=torch.Generator().manual_seed(seed))
+    fdev = [f.to(dev) for f in feats]
+    refs32 = _fp32_runs_prod(lambda: make(lambda sd: sd), lambda t: t.d_step(j(feats), alpha))
+    want = tr.d_step(_d(feats), _d(alpha))
+    got = tf.train_discriminator(FG, FD, d_loss_fn, _Adam(FD.parameters(), lr=0.0, betas=(0.5, 0.999)), fdev, level,
+                                 alpha=alpha.to(dev))
+    for k in want:
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _rel_l2({k: p.grad for k, p in FD.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params, f'prod-fd:B{batch}')
+    for r in refs32:
+        r.g_step(feats)
+    want = tr.g_step(_d(feats))
+    got = tf.train_generator(FG, FD, C, _Adam(FG.parameters(), lr=0.0, betas=(0.5, 0.999)), fdev, level, g_loss_fn, crit, crit)
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+    _rel_l2({k: p.grad for k, p in FG.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params, f'prod-fg:B{batch}')
 
 
 CASES = [('res', 'instance_norm', False), ('res', 'instance_norm', True), ('default', 'batch_norm', False),
@@ -534,7 +665,7 @@ def test_feature_gen_gradients_vs_oracle(dev, case):
                                  alpha=alpha.to(dev))
     for k in want:
         assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    _grads_close({k: p.grad for k, p in FD.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params)
+    _grads_close({k: p.grad for k, p in FD.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params, 'fd:' + '/'.join(map(str, case)))
 
 
 @pytest.mark.parametrize("case", FEATURE_GRAD_CASES[:2])
@@ -570,4 +701,4 @@ def test_feature_gen_generator_gradients_vs_oracle(dev, case):
     assert set(got) == set(want)
     for k in want:
         assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    _grads_close({k: p.grad for k, p in FG.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params)
+    _grads_close({k: p.grad for k, p in FG.named_parameters()}, tr.g, [r.g for r in refs32], tr.g_params, 'fg:' + '/'.join(map(str, case)))

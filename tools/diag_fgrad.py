@@ -5,7 +5,7 @@ import torch
 import test_steps_gpu as T
 dev = torch.device('cuda:0')
 orig = T._grads_close
-def show(named_got, ref64, ref32_list, names):
+def show(named_got, ref64, ref32_list, names, tag=''):
     gmax = max(float(ref64[k].grad.abs().max()) for k in names if ref64[k].grad is not None)
     for k in names:
         if ref64[k].grad is None: continue
