@@ -366,6 +366,23 @@ int sempyr_channel_sum(const float* x, int N, int C, int HW, float scale, float*
 
 
 /* ------------------------------------------------------------------------------------------
+ * Input pipeline on the device: transforms.Resize(256) + CenterCrop(256) + ToTensor of the
+ * reference's ImageFolder (train_model.py:233-238, eval_model.py:45-50) and the two transforms.Normalize maps that follow
+ * (train_model.py:240-247,308-309) for ONE decoded image in one launch.
+ *   src: uint8 [H][W][3] device memory.  htab / vtab: int32 device tables [crop_w][2 + hk] / [crop_h][2 + vk] =
+ *   {first source index, taps, coefficients with 22 fractional bits} of PIL's bilinear ImagingResample for the columns / rows
+ *   the crop keeps (host: imageio.resample_table restates Pillow's precompute_coeffs).  The kernel performs PIL's integer
+ *   arithmetic (horizontal pass, clip to 8 bits, vertical pass, clip): pixels are bit-identical to PIL's.
+ *   out01 (optional): the image in [0,1] (x / 255, correctly rounded), [3][crop_h][crop_w].
+ *   out_a / out_b (optional): (x / 255 - mean[c]) / std[c] with mean_* / std_* = 3 floats each in HOST memory.
+ * ---------------------------------------------------------------------------------------- */
+int sempyr_resize_crop_normalize(const uint8_t* src, int H, int W, int crop_h, int crop_w,
+                                 const int32_t* htab, int hk, const int32_t* vtab, int vk,
+                                 const float* mean_a, const float* std_a, float* out_a,
+                                 const float* mean_b, const float* std_b, float* out_b,
+                                 float* out01, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Replay of a captured loop body (no counterpart in the reference: its loop body, train_model.py:300-349, is issued op by
  * op from Python).  sempyr_replay_create walks a captured hipGraph_t once (kernel / memset / 1-D device memcpy / empty
  * nodes and their dependency edges) and lays the DAG out on up to max_streams HIP streams; sempyr_replay_launch re-issues

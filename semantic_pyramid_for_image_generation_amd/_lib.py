@@ -100,6 +100,8 @@ SIGNATURES = {
     "sempyr_accumulate_many": [ctypes.POINTER(AccumItem), c_int, _P],
     "sempyr_lerp_rows": [_P, _P, _P, _P, c_int, c_int, _P],
     "sempyr_normalize": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "sempyr_resize_crop_normalize": [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, ctypes.POINTER(c_float),
+                                     ctypes.POINTER(c_float), _P, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _P, _P],
     "sempyr_pool2_down": [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P],
     "sempyr_pool2_up": [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P],
     "sempyr_maxpool3s2_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],

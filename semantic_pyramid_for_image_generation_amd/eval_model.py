@@ -56,7 +56,7 @@ def _main():
     classifier = load_classifier(args.classifier_path, device)
     classifier.eval()
 
-    eval_set = imageio.ImageFolder(args.eval_path, image_size=256, crop_size=256)
+    eval_set = imageio.ImageFolder(args.eval_path, image_size=256, crop_size=256, raw=imageio.DEVICE_TRANSFORM)
     normalizer_clf = Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     print('set data loader')
     eval_loader = imageio.make_loader(eval_set, args.batch_size, shuffle=True, num_workers=4, drop_last=True)
@@ -65,7 +65,7 @@ def _main():
     print("Starting Eval Loop...")
     sample_num = 1
     for images, _ in eval_loader:
-        images = images.to(device)
+        images = imageio.batch_images(images, device)
         grid = imageio.make_grid(images, padding=2, normalize=False, nrow=8)
         imageio.save_image(grid, os.path.join(output_images_dir, 'orig_{}.jpg'.format(sample_num)))
         # the reference parses --num-of-noises but always loops range(4) (quirk Q6)

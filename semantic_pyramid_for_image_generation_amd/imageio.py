@@ -1,6 +1,8 @@
 """Host-side I/O the CLIs need and torchvision / tensorboardX used to provide (neither is installed
-here): an ImageFolder with Resize(256)+CenterCrop(256)+ToTensor, a sharded
-loader, make_grid / save_image, and a scalar writer.  None of this is on the timed path."""
+here): an ImageFolder with Resize(256)+CenterCrop(256)+ToTensor -- on the host through PIL, or
+(raw=True + device_batch) decoded on the host and resized / cropped / converted / normalised by ONE GPU launch per image,
+bit-identical to the PIL path --, a sharded loader, make_grid / save_image, and a scalar writer.  None of this is on the timed
+path."""
 import os
 import time
 
@@ -14,7 +16,10 @@ class ImageFolder(torch.utils.data.Dataset):
     """root/<class>/<image> -> (float tensor (3,crop,crop) in [0,1], class index); same transform chain as
     train_model.py:233-238 (shorter side -> image_size, bilinear with antialias; center crop; ToTensor)."""
 
-    def __init__(self, root, image_size=256, crop_size=256):
+    def __init__(self, root, image_size=256, crop_size=256, raw=False):
+        # raw: __getitem__ returns the decoded uint8 (height, width, 3) pixels; resize / crop / ToTensor / Normalize then run on
+        # the GPU (device_transform), batch them with raw_collate
+        self.raw = raw
         classes = sorted(d.name for d in os.scandir(root) if d.is_dir())
         if not classes:
             raise FileNotFoundError(f"Couldn't find any class folder in {root}.")
@@ -35,6 +40,8 @@ class ImageFolder(torch.utils.data.Dataset):
         path, target = self.imgs[index]
         with open(path, 'rb') as f:
             img = Image.open(f).convert('RGB')
+        if self.raw:
+            return torch.from_numpy(np.array(img, dtype=np.uint8)), target
         w, h = img.size
         s = self.image_size
         if w <= h:
@@ -48,13 +55,125 @@ class ImageFolder(torch.utils.data.Dataset):
         return torch.from_numpy(arr).permute(2, 0, 1).float().div(255), target
 
 
+# ------------------------------------------------------------------------------------------------
+# the same transform chain on the GPU (sempyr_resize_crop_normalize): decoded uint8 pixels in, float planes out
+# ------------------------------------------------------------------------------------------------
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def resample_table(in_size, out_size, first, count):
+    """Integer coefficient table of PIL's bilinear ImagingResample (8-bit images) for output positions first .. first+count-1
+    of an in_size -> out_size resize: int32 array [count][2 + ksize] = {first source index, taps, coefficients}.  Follows
+    Pillow's precompute_coeffs / normalize_coeffs_8bpc step by step in double precision (support = max(scale, 1), window
+    [int(center - support + 0.5), int(center + support + 0.5)), triangle weights normalised to 1, 22 fractional bits rounded
+    to nearest), so the device kernel reproduces PIL's pixels exactly."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    tab = np.zeros((count, 2 + ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for i in range(count):
+        xx = first + i
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [max(0.0, 1.0 - abs((x + xmin - center + 0.5) * ss)) for x in range(xmax)]
+        ww = sum(w)
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        tab[i, 0], tab[i, 1] = xmin, xmax
+        for x, v in enumerate(w):
+            tab[i, 2 + x] = int(-0.5 + v * (1 << _PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PRECISION_BITS))
+    return tab, ksize
+
+
+_TABLES = {}
+# the CLIs decode on the host and transform on the GPU unless SEMPYR_DEVICE_TRANSFORM=0 (then PIL does the whole chain)
+DEVICE_TRANSFORM = os.environ.get("SEMPYR_DEVICE_TRANSFORM", "1") != "0"
+
+
+def batch_images(data, device):
+    """The (B,3,crop,crop) float batch in [0,1] on `device` from what a loader of ImageFolder yields: a tensor batch (host
+    transform chain) is uploaded, a list of raw decoded images goes through device_batch."""
+    if isinstance(data, (list, tuple)):
+        return device_batch(data, device)[0]
+    return data.to(device, non_blocking=True)
+
+
+def device_transform(pixels, device, image_size=256, crop_size=256, mean_a=None, std_a=None, mean_b=None, std_b=None,
+                     want01=True, out=None):
+    """Resize(image_size) -> CenterCrop(crop_size) -> ToTensor [-> Normalize(mean_a, std_a)] [-> Normalize(mean_b, std_b)] of ONE
+    decoded image (uint8 array / tensor, height x width x 3) on the GPU, one launch (train_model.py:233-247,308-309).
+    Returns (image in [0,1] or None, copy a or None, copy b or None), each (3, crop, crop) float32 on `device`; `out`: a triple
+    of existing tensors to write into (e.g. rows of a batch).  The pixels are bit-identical to the PIL path of ImageFolder."""
+    import ctypes
+    from . import _lib
+    t = torch.as_tensor(pixels)
+    if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+        raise ValueError("device_transform: a uint8 (height, width, 3) image expected")
+    h, w = int(t.shape[0]), int(t.shape[1])
+    s = image_size
+    if w <= h:
+        nw, nh = s, int(s * h / w)
+    else:
+        nw, nh = int(s * w / h), s
+    if nw < crop_size or nh < crop_size:
+        raise ValueError("device_transform: the resized image is smaller than the crop")
+    left, top = int(round((nw - crop_size) / 2.0)), int(round((nh - crop_size) / 2.0))
+    key = (h, w, nw, nh, left, top, crop_size, str(device))
+    tabs = _TABLES.get(key)
+    if tabs is None:
+        ht, hk = resample_table(w, nw, left, crop_size)
+        vt, vk = resample_table(h, nh, top, crop_size)
+        if len(_TABLES) > 64:
+            _TABLES.clear()
+        tabs = (torch.from_numpy(ht).to(device), hk, torch.from_numpy(vt).to(device), vk)
+        _TABLES[key] = tabs
+    src = t.contiguous().to(device, non_blocking=True)
+    outs = list(out) if out is not None else [None, None, None]
+    want = (want01, mean_a is not None, mean_b is not None)
+    for i in range(3):
+        if want[i] and outs[i] is None:
+            outs[i] = torch.empty(3, crop_size, crop_size, dtype=torch.float32, device=device)
+        if not want[i]:
+            outs[i] = None
+    f3 = ctypes.c_float * 3
+    arg = lambda v: f3(*[float(x) for x in v]) if v is not None else None
+    ptr = lambda x: 0 if x is None else x.data_ptr()
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib.sempyr_resize_crop_normalize(src.data_ptr(), h, w, crop_size, crop_size, tabs[0].data_ptr(), tabs[1],
+                                                         tabs[2].data_ptr(), tabs[3], arg(mean_a), arg(std_a), ptr(outs[1]),
+                                                         arg(mean_b), arg(std_b), ptr(outs[2]), ptr(outs[0]),
+                                                         torch._C._cuda_getCurrentRawStream(torch.device(device).index or 0)),
+                   "sempyr_resize_crop_normalize")
+    return tuple(outs)
+
+
+def raw_collate(batch):
+    """collate_fn for ImageFolder(raw=True): images of different sizes stay a list"""
+    return [b[0] for b in batch], torch.tensor([b[1] for b in batch])
+
+
+def device_batch(raw_images, device, image_size=256, crop_size=256, mean_a=None, std_a=None, mean_b=None, std_b=None):
+    """device_transform of a list of decoded images into batch tensors: ((B,3,crop,crop) in [0,1], copy a, copy b)."""
+    B = len(raw_images)
+    mk = lambda on: torch.empty(B, 3, crop_size, crop_size, dtype=torch.float32, device=device) if on else None
+    x01, xa, xb = mk(True), mk(mean_a is not None), mk(mean_b is not None)
+    for i, img in enumerate(raw_images):
+        device_transform(img, device, image_size, crop_size, mean_a, std_a, mean_b, std_b,
+                         out=(x01[i], None if xa is None else xa[i], None if xb is None else xb[i]))
+    return x01, xa, xb
+
+
 def make_loader(dataset, batch_size, shuffle=True, num_workers=4, drop_last=True, rank=0, world_size=1):
     sampler = None
     if world_size > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, world_size, rank, shuffle=shuffle, drop_last=drop_last)
         shuffle = False
     return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, sampler=sampler, num_workers=num_workers,
-                                       pin_memory=True, drop_last=drop_last)
+                                       pin_memory=True, drop_last=drop_last,
+                                       collate_fn=raw_collate if getattr(dataset, 'raw', False) else None)
 
 
 def make_grid(tensor, nrow=8, padding=2, normalize=False, pad_value=0.0):

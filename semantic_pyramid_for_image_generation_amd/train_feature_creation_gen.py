@@ -85,7 +85,7 @@ def _main():
     device = parallel.init_device()
     rank, world = parallel.rank(), parallel.world_size()
     print("set image folder")
-    train_set = imageio.ImageFolder(args.train_path, image_size=256, crop_size=256)
+    train_set = imageio.ImageFolder(args.train_path, image_size=256, crop_size=256, raw=imageio.DEVICE_TRANSFORM)
     normalizer_clf = Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     print('set data loader')
     train_loader = imageio.make_loader(train_set, args.batch_size, shuffle=True, num_workers=4, drop_last=True,
@@ -145,7 +145,7 @@ def _main():
             if iterations % 30 == 1:
                 print('epoch:', epoch, ', iter', iterations, 'start, time =', time.time() - starting_time, 'seconds')
                 starting_time = time.time()
-            images = images.to(device, non_blocking=True)
+            images = imageio.batch_images(images, device)
             with torch.no_grad():
                 _, features = classifier(normalizer_clf(images))
             features = list(features)

@@ -631,7 +631,7 @@ def _main():
     normalizer_clf = Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     normalizer_discriminator = Normalize([0.5, 0.5, 0.5], [0.5, 0.5, 0.5])
     print("set image folder")
-    train_set = imageio.ImageFolder(args.train_path, image_size=256, crop_size=256)
+    train_set = imageio.ImageFolder(args.train_path, image_size=256, crop_size=256, raw=imageio.DEVICE_TRANSFORM)
     print('set data loader')
     train_loader = imageio.make_loader(train_set, args.batch_size, shuffle=True, num_workers=4, drop_last=True,
                                        rank=rank, world_size=world)
@@ -697,11 +697,17 @@ def _main():
                 print('epoch:', epoch, ', iter', iterations, 'start, time =', time.time() - starting_time, 'seconds')
                 starting_time = time.time()
             images, _ = data
-            # (the pinned host batch goes to the loop as it is: the upload is issued on the loop's prefetch stream, in front of
+            if isinstance(images, (list, tuple)):
+                # raw decoded pixels: Resize / CenterCrop / ToTensor on the GPU (sempyr_resize_crop_normalize), on the loop's
+                # prefetch stream, where the iteration's first consumers run
+                with torch.cuda.stream(ops.prefetch_stream(device)):
+                    images = imageio.batch_images(images, device)
+            # (a pinned host batch goes to the loop as it is: the upload is issued on the loop's prefetch stream, in front of
             # the work that reads it, instead of on this stream behind the previous iteration's backward pass)
             out = loop.iteration(images, log=writer is not None)
             if first_iter and rank == 0:
                 first_iter = False
+                torch.cuda.current_stream(device).wait_stream(ops.prefetch_stream(device))     # (device-transformed images are produced there)
                 with torch.no_grad():       # every tap of the first batch (the loop only computes the taps an iteration reads)
                     _, features = classifier(normalizer_clf(images.to(device)))
                 images_discriminator = out['images_d']

@@ -67,9 +67,10 @@ ALLOW = {
     ('prod-d:default/batch_norm/False', 'conv_block5.conv_block1.block.0.weight'): 4e-4,
     # the same at batch 64 on FeaturesDiscriminator's last residual block (1.6e-4 .. 2.2e-4 measured, bound 1.6e-4 .. 2.1e-4)
     ('prod-fd:B64', 'conv_block5.'): 3e-4,
-    # ... and on LevelUpFeaturesGenerator's first residual block, whose gradients arrive through res_block2's K = 4608 input
-    # gradients and the classifier stage behind it (3.8e-4 .. 4.0e-4 measured against 7.6e-5 for the fp32 CPU runs)
-    ('prod-fg:B64', 'res_block1.'): 6e-4,
+    # ... and on LevelUpFeaturesGenerator at batch 64: every one of its gradients arrives through the K = 4608 .. 8192 input
+    # gradients of the critic's and the classifier stage's convolutions (3.2e-4 .. 4.0e-4 measured on all of its tensors against
+    # 6.5e-5 .. 7.6e-5 for the fp32 CPU runs, i.e. 5 x; at batch 16 the same tensors are inside 3 x)
+    ('prod-fg:B64', ''): 6e-4,
 }
 
 
