@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
+    ap.add_argument('--no-bf16x3', action='store_true', help='skip the separate split-bf16 figure')
     ap.add_argument('--profile-pass', action='store_true',
                     help='run ONLY the single-stream instrumented pass of --steps cycles, bracketed by sempyr_marker_kernel launches '
                          '(for rocprofv3 --kernel-trace; SEMPYR_PROFILE_DUMP=<csv> keeps the per-launch shapes, see tools/roofline_table.py)')
@@ -280,6 +281,29 @@ def main():
             t = torch.tensor([plain], dtype=torch.float64, device='cpu' if torch.distributed.get_backend() == 'gloo' else device)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             plain = float(t.item())
+    # The same K steps with the opt-in split-bf16 convolution arithmetic (SEMPYR_MATH_BF16X3: 3x3 stride-1 convolutions and their
+    # input gradients on the bf16 matrix pipe, own tolerances in tests/test_bf16x3_gpu.py).  A separate figure: it never
+    # replaces `value`, which is exact fp32.
+    bf16x3 = None
+    if not a.profile_pass and not a.no_bf16x3 and world == 1:
+        saved_math = ops.CONV_MATH
+        ops.CONV_MATH = _lib.MATH_BF16X3
+        rs = random.getstate()
+        try:
+            lp16 = make_loop()
+            lp16.prepare()
+            for _ in range(2):
+                cycle(lp16)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                cycle(lp16)
+            barrier()
+            bf16x3 = time.perf_counter() - t1
+            del lp16
+        finally:
+            ops.CONV_MATH = saved_math
+            random.setstate(rs)
     # Kernel durations for the roofline: the SAME K steps run once more with a HIP event pair around every conv launch
     # (recorded on the launch's own stream).  They are not recorded during the headline pass because an event pair per
     # launch keeps consecutive kernels from overlapping (measured: +4 % on the cycle time); `instrumented_ms_per_step`
@@ -357,6 +381,12 @@ def main():
                         "train_model.py:197-209) are not computed: generator._ZeroConv, train_model.live_taps; outputs, losses and "
                         "parameter updates are bit-identical with and without (tests/test_graph_loop_gpu.py)",
                 "value_without": iters * world / plain, "ms_per_step_without": 1000.0 * plain / a.steps}
+        if bf16x3 is not None:
+            out["bf16x3"] = {
+                "what": "opt-in SEMPYR_CONV_MATH=bf16x3: 3x3 stride-1 convolutions and their input gradients as split-bf16 products "
+                        "(hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate); everything else fp32.  Images / losses "
+                        "within 1e-3, gradients within 3x the fp32 path's bound (tests/test_bf16x3_gpu.py).  Not the headline.",
+                "value": iters * world / bf16x3, "ms_per_step": 1000.0 * bf16x3 / a.steps, "unit": "iters/s"}
         if eval_ips is not None:
             out["eval_images_per_sec"] = eval_ips
             out["eval_config"] = "eval_model.py loop, gen-type res, batch 8, 4 levels x 4 noises, classifier pass included, 10 repetitions"

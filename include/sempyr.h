@@ -52,7 +52,15 @@ typedef struct sempyr_conv_desc {
     int32_t Cout, kh, kw;
     int32_t stride, pad;
     int32_t ups;                /* 1: the conv reads nearest-x2-upsampled input (2Hin x 2Win) */
+    int32_t math;               /* SEMPYR_MATH_F32 (0, default): exact fp32 products on v_mfma_f32_32x32x2_f32.
+                                 * SEMPYR_MATH_BF16X3 (opt-in): where the launch's kernel has the variant (3x3 / stride 1 / pad 1
+                                 * FWD and DGRAD on 64-row tiles, channels % 16 == 0) every fp32 operand is split into two bf16
+                                 * values and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+                                 * accumulation (relative error ~2^-17 per product); every other launch computes in fp32.
+                                 * Tensors, packed weights and workspace are fp32 either way. */
 } sempyr_conv_desc;
+
+enum { SEMPYR_MATH_F32 = 0, SEMPYR_MATH_BF16X3 = 1 };
 
 enum { SEMPYR_CONV_FWD = 0, SEMPYR_CONV_DGRAD = 1, SEMPYR_CONV_WGRAD = 2 };
 

@@ -16,13 +16,14 @@ c_int, c_float, c_void_p, c_int64, c_size_t = (ctypes.c_int, ctypes.c_float, cty
 MAX_PHASES = 4
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 NORM_BATCH, NORM_INSTANCE, NORM_LAYER = 0, 1, 2
+MATH_F32, MATH_BF16X3 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Hin", ctypes.c_int32), ("Win", ctypes.c_int32),
                 ("Cout", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32),
-                ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("ups", ctypes.c_int32)]
+                ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("ups", ctypes.c_int32), ("math", ctypes.c_int32)]
 
 
 class ConvPlanInfo(ctypes.Structure):

@@ -116,6 +116,7 @@ struct IgemmParams {
     // patch3x3 kernel, single pass: per (sample, channel) row and group of TN*32 consecutive pixels, (sum, sum of squared
     // deviations from the group's mean) of the values written -- the BatchNorm statistics of the output without a pass over it
     float2* Stats;
+    int math;              // SEMPYR_MATH_*: 1 = split-bf16 products where the launch's kernel has the variant
 };
 
 // UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
@@ -549,6 +550,129 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void igemm_kernel(const IgemmParams
     }
 }
 
+// Epilogue of the patch kernels (as the generic kernel's GATHER epilogue): eval-BatchNorm scale, bias, residual, activation,
+// BatchNorm-statistics partials, store.  acc: the wave's TM x TN accumulator tiles of the 32x32 MFMA layout.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void patch_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int tb,
+                                               int gy0, int gx0, int split, int wm, int wn, int l31, int kh)
+{
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    float* out = p.Out + (size_t)split * p.slab_stride;
+    const bool full_m = (m0 + BM) <= p.M;
+    if (p.scale) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float sv[16];
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                sv[r16] = p.scale[m < p.M ? m : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] *= sv[r16];
+        }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float bv[16];
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
+                bv[r16] = p.bias[m < p.M ? m : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] += bv[r16];
+        }
+    }
+    if (p.res) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * (TN * 32) + j * 32 + l31;
+            const int ry = gy0 + nl / p.CW, rx = gx0 + nl % p.CW, rr = ry * p.QW + rx;
+            const float* rp = p.res_half ? p.res + (size_t)tb * (p.OCHW >> 2) + (ry >> 1) * (p.OW >> 1) + (rx >> 1)
+                                         : p.res + (size_t)tb * p.OCHW + rr;
+            const int rstride = p.res_half ? (p.OHW >> 2) : p.OHW;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                    acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * rstride];
+                }
+            }
+        }
+    }
+    if (p.act != SEMPYR_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] = act_apply(acc[i][j][r16], p.act, p.slope);
+    }
+    if (p.Stats) {
+        // Two passes over the accumulators (sum, then squared deviations from the group's own mean: no cancellation), each
+        // closed by a 32-lane butterfly: quad permutes, the two row mirrors and a swizzle across the 16-lane rows.
+        constexpr int GR = TN * 32;
+        const int G = p.QHW / GR;
+        // the wave's TN*32 columns are GR consecutive pixels of one row of the block (CW % GR == 0)
+        const int nl0 = wn * GR;
+        const int g = ((gy0 + nl0 / p.CW) * p.QW + gx0 + nl0 % p.CW) / GR;
+        auto sum32 = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+            return v;
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                float sm = acc[i][0][r16];
+#pragma unroll
+                for (int j = 1; j < TN; ++j) sm += acc[i][j][r16];
+                sm = sum32(sm);
+                const float mu = sm * (1.f / GR);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { const float dv = acc[i][j][r16] - mu; q = fmaf(dv, dv, q); }
+                q = sum32(q);
+                const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                if (l31 == 0 && m < p.M) p.Stats[((size_t)tb * p.M + m) * G + g] = make_float2(sm, q);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * (TN * 32) + j * 32 + l31;
+        const int r = (gy0 + nl / p.CW) * p.QW + gx0 + nl % p.CW;        // the tile lies inside sample tb
+        float* op = out + (size_t)tb * p.OCHW + r;           // stride-1 output: OHW == QHW, pixel r of the plane
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+            if (full_m) {
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) op[(size_t)(mb + (r16 & 3) + 8 * (r16 >> 2)) * p.OHW] = acc[i][j][r16];
+            } else {
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
+                    if (m < p.M) op[(size_t)m * p.OHW] = acc[i][j][r16];
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolutions (FWD incl. fused x2 upsample, and their DGRAD): the input patch of a tile is staged
 // in LDS ONCE per group of PCG channels and the nine taps read it as shifted views, instead of gathering a fresh
@@ -729,121 +853,213 @@ __global__ __launch_bounds__(256, IGEMM_OCC) void patch3x3_kernel(const IgemmPar
         }
     }
 
-    // epilogue (as the generic kernel's GATHER epilogue)
-    float* out = p.Out + (size_t)split * p.slab_stride;
-    const bool full_m = (m0 + BM) <= p.M;
-    if (p.scale) {
+    patch_epilogue<BM, BN, WM, WN>(p, acc, m0, tb, gy0, gx0, split, wm, wn, l31, kh);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same convolutions on the bf16 matrix pipe (sempyr_conv_desc.math = SEMPYR_MATH_BF16X3, opt-in): every fp32 operand is
+// split into two bf16 values, x = hi + lo with hi = bf16(x) and lo = bf16(x - hi) (16 significant bits together), and a
+// product is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- three bf16 MFMAs of
+// 32 cycles each per 16 reduction indices where the fp32 instruction needs eight of 64 cycles (5.3x fewer matrix-pipe
+// cycles); the dropped lo*lo term and the split's own rounding leave a relative error of ~2^-17 per product.
+// Staging: 16 channels per group.  The split happens ONCE per staged element (the 9 taps reuse it): patch positions and
+// weight rows are written to LDS as 16-byte vectors of 8 consecutive channels, [k-half][position] resp. [tap][k-half][m], hi
+// and lo images apart, so an MFMA operand is one ds_read_b128 and 16 lanes of a read group touch 64 distinct banks.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BCG = 16;                                     // channels per staged group (one MFMA reduction block)
+
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float sv[16];
-#pragma unroll
-            for (int r16 = 0; r16 < 16; ++r16) {
-                const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
-                sv[r16] = p.scale[m < p.M ? m : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] *= sv[r16];
-        }
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(x[j] - (float)h);
     }
-    if (p.bias) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float bv[16];
-#pragma unroll
-            for (int r16 = 0; r16 < 16; ++r16) {
-                const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * kh;
-                bv[r16] = p.bias[m < p.M ? m : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] += bv[r16];
-        }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void patch3x3_bf16x3_kernel(const IgemmParams p)
+{
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NSP = 2, PITCH = NSP * 256;               // patch positions per channel-half image
+    constexpr int A_ITEMS = 9 * 2 * BM;                     // (tap, k-half, m) vectors of 8 channels
+    constexpr int A_PER = (A_ITEMS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    bf16x8* const Ahi = reinterpret_cast<bf16x8*>(psm);     // [tap][half][m]
+    bf16x8* const Alo = Ahi + A_ITEMS;
+    bf16x8* const Phi = Alo + A_ITEMS;                      // [half][position]
+    bf16x8* const Plo = Phi + 2 * PITCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    const int MT = p.Mpad / BM;
+    int id = blockIdx.x, split = 0, m_tile, n_tile;
+    if (p.nsplits > 1) {
+        split = id % p.nsplits; id /= p.nsplits;
+        m_tile = id % MT; n_tile = id / MT;
+    } else {
+        const int xcd = id & 7; id >>= 3;
+        m_tile = id % MT;
+        n_tile = (id / MT) * 8 + xcd;
     }
-    if (p.res) {
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    if (n0 >= p.N) return;                                  // uniform (N % BN == 0: no ragged tile)
+
+    // tile geometry: exactly patch3x3_kernel's
+    const int tb = n0 / p.QHW;
+    const int tt = (n0 - tb * p.QHW) / BN;
+    const int tpr = p.QW / p.CW;
+    const int trow = tt / tpr, tcol = tt - trow * tpr;
+    const int gy0 = trow * (BN / p.CW), gx0 = tcol * p.CW;
+    const int s = p.ups;
+    const int pr0 = (gy0 - 1) >> s, pc0 = (gx0 - 1) >> s;
+    const int PW = p.PW, PRPW = p.PR * p.PW;
+    const int XH = p.GH >> s;
+    const ctab_ptr ctab = (ctab_ptr)p.ktab;
+    const int C = p.C;
+
+    // per-lane patch positions (+ the lane's k-half image) of the 9 taps for the lane's TN operand columns, two per register
+    static_assert(TN <= 2, "tap offsets are packed two per register");
+    unsigned off[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int pk = ctab[2 * (t * C) + 1];
+        const int dy = pk >> 16, dx = (int)(short)(pk & 0xffff);
+        unsigned packed = 0u;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn * (TN * 32) + j * 32 + l31;
-            const int ry = gy0 + nl / p.CW, rx = gx0 + nl % p.CW, rr = ry * p.QW + rx;
-            const float* rp = p.res_half ? p.res + (size_t)tb * (p.OCHW >> 2) + (ry >> 1) * (p.OW >> 1) + (rx >> 1)
-                                         : p.res + (size_t)tb * p.OCHW + rr;
-            const int rstride = p.res_half ? (p.OHW >> 2) : p.OHW;
+            const int r = nl / p.CW, c = nl - r * p.CW;
+            const int o = (((gy0 + r + dy) >> s) - pr0) * PW + (((gx0 + c + dx) >> s) - pc0) + kh * PITCH;
+            packed |= (unsigned)o << (16 * j);
+        }
+        off[t] = packed;
+    }
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    unsigned pvoff[NSP];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+    for (int i = 0; i < NSP; ++i) {
+        const int pos = tid + 256 * i;
+        const int pr = pos / PW, pc = pos - pr * PW;
+        const int sy = pr0 + pr, sx = pc0 + pc;
+        const bool ok = pos < PRPW && (unsigned)sy < (unsigned)XH && (unsigned)sx < (unsigned)p.XW;   // else: zero-filled
+        pvoff[i] = ok ? 4u * (unsigned)(tb * p.XCHW + sy * p.XW + sx) : OOB;
+    }
+    // weight items: item = tid + 256 r -> (tap, half, m); the 8 channels of an item are 8 rows of the k-major packed weights
+    int a_off[A_PER];
 #pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) {
-                    const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
-                    acc[i][j][r16] += rp[(size_t)(m < p.M ? m : 0) * rstride];
+    for (int i = 0; i < A_PER; ++i) {
+        const int item = tid + i * 256;
+        const int it = item < A_ITEMS ? item : item - A_ITEMS;      // surplus threads of the last round re-read round 0's data
+        const int th = it / BM, m = it - th * BM;
+        a_off[i] = ((th >> 1) * C + (th & 1) * 8) * p.Mpad + m0 + m;
+    }
+
+    const int ngroups = C / BCG;
+    const int gps = (ngroups + p.nsplits - 1) / p.nsplits;
+    const int g_begin = split * gps, g_end = min(g_begin + gps, ngroups);
+
+    float rp[NSP][BCG];
+    float ra[A_PER][8];
+    auto load_group = [&](int g) {
+        const float* ab = p.A + (size_t)g * BCG * p.Mpad;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ra[i][j] = ab[a_off[i] + j * p.Mpad];
+        const int cb = g * BCG * p.XHW * 4;
+#pragma unroll
+        for (int i = 0; i < NSP; ++i)
+#pragma unroll
+            for (int ci = 0; ci < BCG; ++ci)
+                rp[i][ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (int)pvoff[i], cb + ci * p.XHW * 4, 0));
+    };
+    auto store_group = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int item = tid + i * 256;
+            if (item < A_ITEMS) {
+                bf16x8 h, l;
+                split_bf16x8(ra[i], h, l);
+                Ahi[item] = h; Alo[item] = l;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) {
+            const int pos = tid + 256 * i;
+            if (pos < PRPW) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float x8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x8[j] = rp[i][hf * 8 + j];
+                    bf16x8 h, l;
+                    split_bf16x8(x8, h, l);
+                    Phi[hf * PITCH + pos] = h; Plo[hf * PITCH + pos] = l;
                 }
             }
         }
-    }
-    if (p.act != SEMPYR_ACT_NONE) {
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) acc[i][j][r16] = act_apply(acc[i][j][r16], p.act, p.slope);
-    }
-    if (p.Stats) {
-        // Two passes over the accumulators (sum, then squared deviations from the group's own mean: no cancellation), each
-        // closed by a 32-lane butterfly: quad permutes, the two row mirrors and a swizzle across the 16-lane rows.
-        constexpr int GR = TN * 32;
-        const int G = p.QHW / GR;
-        // the wave's TN*32 columns are GR consecutive pixels of one row of the block (CW % GR == 0)
-        const int nl0 = wn * GR;
-        const int g = ((gy0 + nl0 / p.CW) * p.QW + gx0 + nl0 % p.CW) / GR;
-        auto sum32 = [](float v) {
-            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
-            return v;
-        };
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (g_begin < g_end) {
+        load_group(g_begin);
+        store_group();
+        __syncthreads();
+        const int arow = kh * BM + wm * (TM * 32) + l31;    // + tap * 2 * BM + i * 32
+        for (int g = g_begin; g < g_end; ++g) {
+            const bool more = (g + 1) < g_end;
+            if (more) load_group(g + 1);                    // in flight under the 9 x 3 x TM x TN MFMAs of this group
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
+            for (int i = 0; i < TM; ++i) { ah[0][i] = Ahi[arow + i * 32]; al[0][i] = Alo[arow + i * 32]; }
 #pragma unroll
-            for (int r16 = 0; r16 < 16; ++r16) {
-                float sm = acc[i][0][r16];
+            for (int j = 0; j < TN; ++j) { const int o = (off[0] >> (16 * j)) & 0xffffu; bh[0][j] = Phi[o]; bl[0][j] = Plo[o]; }
 #pragma unroll
-                for (int j = 1; j < TN; ++j) sm += acc[i][j][r16];
-                sm = sum32(sm);
-                const float mu = sm * (1.f / GR);
-                float q = 0.f;
+            for (int t = 0; t < 9; ++t) {
+                const int cur = t & 1, nxt = cur ^ 1;
+                if (t + 1 < 9) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) { const float dv = acc[i][j][r16] - mu; q = fmaf(dv, dv, q); }
-                q = sum32(q);
-                const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
-                if (l31 == 0 && m < p.M) p.Stats[((size_t)tb * p.M + m) * G + g] = make_float2(sm, q);
-            }
-        }
-    }
+                    for (int i = 0; i < TM; ++i) {
+                        ah[nxt][i] = Ahi[(t + 1) * 2 * BM + arow + i * 32]; al[nxt][i] = Alo[(t + 1) * 2 * BM + arow + i * 32];
+                    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nl = wn * (TN * 32) + j * 32 + l31;
-        const int r = (gy0 + nl / p.CW) * p.QW + gx0 + nl % p.CW;        // the tile lies inside sample tb
-        float* op = out + (size_t)tb * p.OCHW + r;           // stride-1 output: OHW == QHW, pixel r of the plane
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * kh;
-            if (full_m) {
-#pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) op[(size_t)(mb + (r16 & 3) + 8 * (r16 >> 2)) * p.OHW] = acc[i][j][r16];
-            } else {
-#pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) {
-                    const int m = mb + (r16 & 3) + 8 * (r16 >> 2);
-                    if (m < p.M) op[(size_t)m * p.OHW] = acc[i][j][r16];
+                    for (int j = 0; j < TN; ++j) {
+                        const int o = (off[t + 1] >> (16 * j)) & 0xffffu;
+                        bh[nxt][j] = Phi[o]; bl[nxt][j] = Plo[o];
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        // small terms first, then the leading product
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][i], bl[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+                    }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                // every wave is done reading this group's images
+            if (more) { store_group(); __syncthreads(); }
         }
     }
+    patch_epilogue<BM, BN, WM, WN>(p, acc, m0, tb, gy0, gx0, split, wm, wn, l31, kh);
 }
 
 // GATHER-mode convolution with at most 4 output rows (RGB image heads: generator last conv, critic/classifier stem
@@ -1418,6 +1634,7 @@ inline int check_desc(const sempyr_conv_desc* d, Geometry& g) {
     if (d->stride != 1 && d->stride != 2) SEMPYR_FAIL("conv: stride %d unsupported (1 or 2)", d->stride);
     if (d->pad < 0 || d->pad > 7) SEMPYR_FAIL("conv: pad %d unsupported", d->pad);
     if (d->ups != 0 && d->ups != 1) SEMPYR_FAIL("conv: ups must be 0/1");
+    if (d->math != SEMPYR_MATH_F32 && d->math != SEMPYR_MATH_BF16X3) SEMPYR_FAIL("conv: unknown math mode %d", d->math);
     g.GHin = d->Hin << d->ups; g.GWin = d->Win << d->ups;
     if (g.GHin + 2 * d->pad < d->kh || g.GWin + 2 * d->pad < d->kw) SEMPYR_FAIL("conv: kernel larger than padded input");
     g.Ho = (g.GHin + 2 * d->pad - d->kh) / d->stride + 1;
@@ -1624,6 +1841,16 @@ int launch_patch(const IgemmParams& p, int splits, hipStream_t st) {
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
+    if constexpr (BM == 64) {
+        // opt-in split-bf16 variant: 64-row tiles with at most 512 patch positions and 16-channel groups
+        if (p.math == SEMPYR_MATH_BF16X3 && nsp == 2 && p.C % BCG == 0) {
+            const size_t lds16 = (size_t)(2 * 9 * 2 * BM + 2 * 2 * 512) * 16;
+            hipLaunchKernelGGL((patch3x3_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), lds16, st, pp);
+            if (e1) (void)hipEventRecord(e1, st);
+            SEMPYR_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (nsp == 2) hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, st, pp);
     else if (nsp == 3) hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, st, pp);
     else hipLaunchKernelGGL((patch3x3_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), lds, st, pp);
@@ -1906,6 +2133,7 @@ static int conv2d_fwd_impl(const sempyr_conv_desc* d, const float* x, const floa
     hipStream_t st = (hipStream_t)stream;
     const long long out_numel = (long long)d->B * d->Cout * pl.Ho * pl.Wo;
     IgemmParams p{};
+    p.math = d->math;
     p.A = wp; p.X = x; p.ktab = reinterpret_cast<const int2*>(ktab);
     p.M = d->Cout; p.Mpad = pl.Mpad; p.N = d->B * pl.Ho * pl.Wo; p.K = pl.K[0]; p.Kpad = pl.Kpad[0];
     p.XCHW = d->Cin * d->Hin * d->Win; p.XW = d->Win; p.XHW = d->Hin * d->Win;
@@ -2006,6 +2234,7 @@ static int conv2d_dgrad_impl(const sempyr_conv_desc* d, const float* gy, const f
     }
     // all stride phases in ONE launch (they share M, the weight layout and the split count)
     IgemmParams p{};
+    p.math = d->math;
     p.A = wp; p.X = gy; p.ktab = reinterpret_cast<const int2*>(ktab);
     p.M = d->Cin; p.Mpad = pl.Mpad;
     p.XCHW = d->Cout * pl.Ho * pl.Wo; p.XW = pl.Wo; p.XHW = pl.Ho * pl.Wo; p.GH = pl.Ho; p.GW = pl.Wo; p.ups = 0;

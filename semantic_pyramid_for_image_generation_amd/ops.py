@@ -358,11 +358,12 @@ class _ModePlan:
 class ConvPlan:
     """Geometry + device tables of one Conv2d shape (cached per shape and device)."""
 
-    def __init__(self, key, device):
+    def __init__(self, key, device, math=0):
         B, Cin, Hin, Win, Cout, kh, kw, stride, pad, ups = key
         self.key = key
         self.device = device
-        self.desc = _lib.ConvDesc(B, Cin, Hin, Win, Cout, kh, kw, stride, pad, ups)
+        self.math = math
+        self.desc = _lib.ConvDesc(B, Cin, Hin, Win, Cout, kh, kw, stride, pad, ups, math)
         self.desc_ref = ctypes.byref(self.desc)
         self.modes = {}
         info = self.mode(CONV_FWD).info
@@ -400,16 +401,21 @@ class ConvPlan:
 
 _PLANS = {}
 _PLANS_LOCK = threading.Lock()
+# Arithmetic of the convolutions (sempyr_conv_desc.math).  0: exact fp32 MFMA everywhere (the measured / default path).
+# 1 (SEMPYR_CONV_MATH=bf16x3, opt-in): 3x3 stride-1 convolutions and their input gradients form every product from split-bf16
+# operands on the bf16 matrix pipe (~2^-17 relative error per product); everything else stays fp32.  Read when a plan is
+# looked up, so it can be switched at run time (tests, bench.py's separate bf16x3 figure).
+CONV_MATH = _lib.MATH_BF16X3 if os.environ.get("SEMPYR_CONV_MATH", "f32").lower() in ("bf16x3", "1") else _lib.MATH_F32
 
 
 def get_plan(key, device):
-    k = (key, device.index)
+    k = (key, device.index, CONV_MATH)
     p = _PLANS.get(k)
     if p is None:
         with _PLANS_LOCK:
             p = _PLANS.get(k)
             if p is None:
-                p = ConvPlan(key, device)
+                p = ConvPlan(key, device, CONV_MATH)
                 _PLANS[k] = p
     return p
 

@@ -77,6 +77,8 @@ ALLOW = {
 def _allowance(tag, k, tol):
     for (t, prefix), bound in ALLOW.items():
         if t == tag and k.startswith(prefix):
+            if isinstance(bound, tuple):          # ('factor', f): f times the measured bound (tests of the split-bf16 variant)
+                return tol * bound[1]
             return max(tol, bound)
     return tol
 
