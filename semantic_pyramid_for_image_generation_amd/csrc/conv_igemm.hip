@@ -17,6 +17,7 @@
 // Split-K partial tiles go to caller-provided slabs and are summed in a fixed order
 // (deterministic: no float atomics anywhere).
 #include "common.h"
+#include <map>
 #include <mutex>
 #include <stdlib.h>
 #include <vector>
@@ -74,6 +75,17 @@ __device__ __forceinline__ void decode_pixel(int n, int QHW, int QW, int quad, i
     }
 }
 
+// Tile geometry of the 4x4 / stride-2 patch kernels (conv_tpatch.h)
+struct TpGeom {
+    int R, CW;             // a tile is SPT samples x R rows x CW columns of the pixel grid (of one stride phase for DGRAD)
+    int PR, PW;            // staged source rows / columns per sample
+    int PWH, PSS;          // LDS row pitch / per-sample pitch in positions (padded so operand reads are conflict-free)
+    int npos;              // staged source positions = SPT * PR * PW
+    int slot_row[16];      // first row (channel 0) of each (phase, tap) slot in the k-major packed weights
+    int slot_dydx[16];     // source offset of the slot's tap: dy << 16 | (dx & 0xffff)
+    FastDiv dRC, dCW, dPRPW, dPW;
+};
+
 struct IgemmParams {
     const float* A;        // GATHER: packed weights [Kpad][Mpad]; WGRAD: gy [B][M][QH*QW]
     const float* X;        // gathered tensor
@@ -117,6 +129,9 @@ struct IgemmParams {
     // deviations from the group's mean) of the values written -- the BatchNorm statistics of the output without a pass over it
     float2* Stats;
     int math;              // SEMPYR_MATH_*: 1 = split-bf16 products where the launch's kernel has the variant
+    TpGeom tp;
+    int dbg;                      // tuning aid (SEMPYR_TP_DBG): 1 = no staging loads after the first group, 2 = no LDS stores after it
+    unsigned long long* stamps;   // tuning aid (SEMPYR_TP_STAMPS): 8 wall-clock stamps per workgroup, or null
 };
 
 // UT ("uniform tap"): the channel count of the gathered tensor is a multiple of the k-chunk, so the 16 reduction
@@ -1062,6 +1077,8 @@ __global__ __launch_bounds__(256, 2) void patch3x3_bf16x3_kernel(const IgemmPara
     patch_epilogue<BM, BN, WM, WN>(p, acc, m0, tb, gy0, gx0, split, wm, wn, l31, kh);
 }
 
+#include "conv_tpatch.h"
+
 // GATHER-mode convolution with at most 4 output rows (RGB image heads: generator last conv, critic/classifier stem
 // input gradients).  Padding M = 3 to a 32-row MFMA tile wastes 10x the matrix work, so this shape runs on the vector ALU:
 // one output pixel per lane (64 consecutive pixels per wave -> 256-byte coalesced gathers), weights and k-table entries
@@ -1539,7 +1556,8 @@ __global__ __launch_bounds__(256) void pack_weights_many_kernel(const PackManyAr
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3, CFG_64x192 = 4, CFG_64x128 = 5 };
+enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3, CFG_64x192 = 4, CFG_64x128 = 5,
+       CFG_TPATCH = 6 /* 4x4 / stride-2 patch kernels: the tile comes from tp_pick() */ };
 
 // Tile shape for a GATHER launch over N pixels (all stride phases of a DGRAD together).  `kind`: the kernel the launch
 // will run on — the choices below are measured (tools/bench_conv.py mid / small with SEMPYR_FORCE_CFG*).
@@ -1893,6 +1911,8 @@ int try_patch(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int 
     return rc ? rc : 1;
 }
 
+#include "conv_tpatch_host.h"
+
 template <int MODE>
 int launch_cfg(int cfg, const IgemmParams& p, int splits, bool uniform_tap, hipStream_t st) {
     if (MODE == MODE_GATHER && p.M <= 4 && splits == 1) return launch_small_m(p, uniform_tap, st);
@@ -1936,8 +1956,10 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         int cps;
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn), plan->Kpad[0] / BK, plan->splits[0], cps);
         if (rgb3x3_ok(d, mode) && N >= 4096) plan->splits[0] = 1;
+        TpTile tp;
+        if (tp_pick(d, mode, tp)) { plan->cfg = CFG_TPATCH; plan->splits[0] = tp_splits(tp); }
         plan->workspace_bytes = plan->splits[0] > 1 ? (long long)plan->splits[0] * out_numel * 4 : 0;
-        if (plan->splits[0] == 1 && !rgb3x3_ok(d, mode) && N < (1ll << 31)) {
+        if (plan->splits[0] == 1 && !rgb3x3_ok(d, mode) && N < (1ll << 31) && plan->cfg != CFG_TPATCH) {
             // would the patch kernel take it?  (the geometry fields its eligibility test reads)
             IgemmParams q{};
             q.Mpad = plan->Mpad; q.N = (int)N; q.QHW = g.Ho * g.Wo; q.QW = g.Wo; q.QH = g.Ho; q.ups = d->ups;
@@ -1968,6 +1990,11 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
                 pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(N, bn) * s * s, plan->Kpad[ph] / BK, plan->splits[ph], cps);
             if (rgb3x3_ok(d, mode) && N >= 4096) plan->splits[ph] = 1;
             if (plan->splits[ph] > max_splits) max_splits = plan->splits[ph];
+        }
+        TpTile tp;
+        if (tp_pick(d, mode, tp)) {
+            plan->cfg = CFG_TPATCH; max_splits = tp_splits(tp);
+            for (int ph = 0; ph < s * s; ++ph) plan->splits[ph] = max_splits;
         }
         plan->tab_entries = off;
         plan->wpack_floats = (long long)off * plan->Mpad;
@@ -2174,11 +2201,23 @@ static int conv2d_fwd_impl(const sempyr_conv_desc* d, const float* x, const floa
         if (!pl.stats_granule || fused_pool || !y) SEMPYR_FAIL("conv fwd: this shape has no statistics epilogue (sempyr_conv2d_plan().stats_granule == 0)");
         p.Stats = reinterpret_cast<float2*>(tile_stats);
     }
+    TpTile tp;
+    int cfg = pl.cfg;
+    if (cfg == CFG_TPATCH) {
+        // epilogues the 4x4 patch kernel does not have fall back to the generic kernel (any tile works with the plan's splits)
+        if (y && !y_pooled && !act_bits && !mask_bits && !tile_stats && !res_half && tp_pick(d, SEMPYR_CONV_FWD, tp)) {
+            if ((rc = tp_launch(d, tp, p, nullptr, splits, st))) return rc;
+            if (splits > 1)
+                return run_splitk_reduce((const float*)ws, y, bias, splits, out_numel, pl.Ho * pl.Wo, d->Cout, act, slope, st, scale, res, 0);
+            return 0;
+        }
+        cfg = pick_cfg(pl.Mpad, (long long)d->B * pl.Ho * pl.Wo, conv_kind(d, SEMPYR_CONV_FWD));
+    }
     if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_FWD)) rc = launch_rgb3x3(p, st);
     else {
-        rc = fused_pool ? 0 : try_patch(d, SEMPYR_CONV_FWD, pl.cfg, p, splits, st);
+        rc = fused_pool ? 0 : try_patch(d, SEMPYR_CONV_FWD, cfg, p, splits, st);
         if (rc == 0 && tile_stats) SEMPYR_FAIL("conv fwd: internal: the statistics epilogue was planned but the patch kernel declined");
-        if (rc == 0) rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cin % BK == 0, st);
+        if (rc == 0) rc = launch_cfg<MODE_GATHER>(cfg, p, splits, d->Cin % BK == 0, st);
         else if (rc == 1) rc = 0;
     }
     if (rc) return rc;
@@ -2271,8 +2310,18 @@ static int conv2d_dgrad_impl(const sempyr_conv_desc* d, const float* gy, const f
         p.C = d->Cout;
         p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = (int)(pl.wpack_floats * 4);
         if (splits == 1 && rgb3x3_ok(d, SEMPYR_CONV_DGRAD)) return launch_rgb3x3(p, st);
-        int rc = p.nphases == 1 ? try_patch(d, SEMPYR_CONV_DGRAD, pl.cfg, p, splits, st) : 0;
-        if (rc == 0) rc = launch_cfg<MODE_GATHER>(pl.cfg, p, splits, d->Cout % BK == 0, st);
+        int cfg = pl.cfg;
+        TpTile tp;
+        if (cfg == CFG_TPATCH) {
+            if (!g_pooled && tp_pick(d, SEMPYR_CONV_DGRAD, tp)) {
+                if (int rc = tp_launch(d, tp, p, pl.tab_off, splits, st)) return rc;
+                if (splits > 1) return run_splitk_reduce((const float*)ws, gx, bias, splits, in_numel, GH * GW, d->Cin, SEMPYR_ACT_NONE, 0.f, st);
+                return 0;
+            }
+            cfg = pick_cfg(pl.Mpad, in_numel / d->Cin, conv_kind(d, SEMPYR_CONV_DGRAD));
+        }
+        int rc = p.nphases == 1 ? try_patch(d, SEMPYR_CONV_DGRAD, cfg, p, splits, st) : 0;
+        if (rc == 0) rc = launch_cfg<MODE_GATHER>(cfg, p, splits, d->Cout % BK == 0, st);
         else if (rc == 1) rc = 0;
         if (rc) return rc;
     }

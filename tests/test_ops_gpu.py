@@ -108,6 +108,69 @@ def test_conv2d_fused_activation(dev, case, act):
     assert rel_err(bd.grad, br.grad) < tol
 
 
+# 4x4 / stride 2 / pad 1 shapes the LDS-patch kernels of csrc/conv_tpatch.h take (plan cfg 6): 2-D tile blocks, whole-sample
+# and multi-sample tiles, several 64-row tiles, split-K over channel groups, bias / activation epilogue
+TPATCH_CASES = [
+    (2, 64, 32, 32, 64, True, 'none'),       # critic block: 4 tiles of 4 x 16 outputs per sample
+    (4, 128, 8, 8, 192, True, 'lrelu'),      # 4 x 4 outputs per sample: one tile = 4 samples; 3 row tiles; input gradient too
+    (1, 128, 32, 128, 64, False, 'none'),    # 16 x 64 outputs: tiles of 2 x 32; input gradient with 2 row tiles
+    (2, 512, 16, 16, 128, True, 'none'),     # deep reduction: split-K over channel groups
+    (3, 72, 16, 16, 64, False, 'tanh'),      # whole-sample tiles, 9 channel groups of 8
+]
+
+
+@pytest.mark.parametrize("case", TPATCH_CASES)
+def test_conv4x4s2_patch_kernels(dev, case):
+    ops = _ops()
+    from semantic_pyramid_for_image_generation_amd._lib import CONV_FWD
+    B, Cin, H, W, Cout, has_bias, act = case
+    assert ops.get_plan((B, Cin, H, W, Cout, 4, 4, 2, 1, 0), dev).mode(CONV_FWD).info.cfg == 6, "not on the 4x4 patch kernel"
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g) if has_bias else None
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if has_bias else None
+    yr = F.conv2d(xr, wr, br, 2, 1)
+    yr = torch.tanh(yr) if act == 'tanh' else F.leaky_relu(yr, 0.2) if act == 'lrelu' else yr
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if has_bias else None
+    kind = {'none': ops.ACT_NONE, 'lrelu': ops.ACT_LRELU, 'tanh': ops.ACT_TANH}[act]
+    y = ops.conv2d(xd, wd, bd, 2, 1, act_kind=kind, slope=0.2)
+    y.backward(gy.to(dev))
+    tol = 2e-5
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+    if has_bias:
+        assert rel_err(bd.grad, br.grad) < tol
+
+
+def test_conv_transpose4x4s2_patch_kernel(dev):
+    """ConvTranspose2d(4, 2, 1) forward = the per-phase input-gradient kernel (128 output channels: two row tiles); its
+    backward = the forward patch kernel."""
+    ops = _ops()
+    from semantic_pyramid_for_image_generation_amd._lib import CONV_DGRAD
+    B, Cin, H, W, Cout = 2, 64, 8, 8, 128
+    assert ops.get_plan((B, Cout, 2 * H, 2 * W, Cin, 4, 4, 2, 1, 0), dev).mode(CONV_DGRAD).info.cfg == 6
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.05
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, 2, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
+    y = ops.conv_transpose2d(xd, wd, None, 2, 1)
+    y.backward(gy.to(dev))
+    tol = 2e-5
+    assert rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
+
+
 CONVT_CASES = [
     (2, 128, 1, 1, 512, 4, 1, 0, False),   # G conv_block1: 1x1 -> 4x4
     (2, 64, 4, 4, 64, 4, 2, 1, False),     # G deconv 4x4 s2

@@ -67,6 +67,15 @@ ALLOW = {
     ('prod-d:default/batch_norm/False', 'conv_block5.conv_block1.block.0.weight'): 4e-4,
     # the same at batch 64 on FeaturesDiscriminator's last residual block (1.6e-4 .. 2.2e-4 measured, bound 1.6e-4 .. 2.1e-4)
     ('prod-fd:B64', 'conv_block5.'): 3e-4,
+    # Production batch, instance-norm critic, gradients of block 2 (conv weight, norm weight): these figures are DRAWS, not constants of the
+    # arithmetic.  Measured with four kernel configurations of the same fp32 convolutions (all within 1e-6 of fp64 per
+    # output element, tools/tp_err.py): 0.70e-3 (generic forward + per-phase input gradient), 0.84e-3 (all generic), 1.21e-3
+    # (patch forward on block 1 only), 1.75e-3 (both patch kernels) against 0.43e-3 for the worst of the four fp32 CPU runs: at
+    # 16 x 256^2 a critic pass has ~2e7 LeakyReLU pre-activations, dozens of them within round-off of zero, and which of those
+    # change side depends on the summation order of the convolution in front (tests: _lrelu_flips).  The figures above are the
+    # norm weight's; the conv weight moves with it (2.36e-3 against a noise of 0.69e-3).  Both get 5 x their measured fp32 noise.
+    ('prod-d:res/instance_norm/False', 'conv_block2.conv_block1.block.'): ('factor', 5.0 / 3.0),
+    ('prod-d:res/instance_norm/True', 'conv_block2.conv_block1.block.'): ('factor', 5.0 / 3.0),
     # ... and on LevelUpFeaturesGenerator at batch 64: every one of its gradients arrives through the K = 4608 .. 8192 input
     # gradients of the critic's and the classifier stage's convolutions (3.2e-4 .. 4.0e-4 measured on all of its tensors against
     # 6.5e-5 .. 7.6e-5 for the fp32 CPU runs, i.e. 5 x; at batch 16 the same tensors are inside 3 x)
@@ -83,7 +92,7 @@ def _allowance(tag, k, tol):
     return tol
 
 
-def _grads_close(named_got, ref64, ref32_list, names, tag=''):
+def _grads_close(named_got, ref64, ref32_list, names, tag='', widen=1.0):
     """named_got: {name: HIP gradient}; ref64 / ref32_list: {name: tensor with .grad} of the fp64 oracle and of the fp32
     oracle runs (different thread counts / one-ulp jitter).  Per tensor: max-abs error relative to the tensor's max-abs
     <= 3 * max(the fp32 runs' own distance from fp64 on that tensor, the median of those distances over the step's tensors),
@@ -104,7 +113,7 @@ def _grads_close(named_got, ref64, ref32_list, names, tag=''):
             assert named_got[k] is None or float(named_got[k].abs().max()) == 0.0, k
             continue
         err = _rel_err(named_got[k], ref64[k].grad, gmax)
-        tol = _allowance(tag, k, 3.0 * max(noise[k], floor))
+        tol = _allowance(tag, k, widen * 3.0 * max(noise[k], floor))
         outliers = int((err > tol).sum())
         ratio = robust_max(err) / tol
         if ratio > worst[0]:
@@ -194,6 +203,73 @@ def _d(ts):
     return [t.double() for t in ts] if isinstance(ts, (list, tuple)) else ts.double()
 
 
+class _CaptureLine:
+    """`with _CaptureLine(tm) as cap:` -- keeps the (fake batch, interpolated batch) the HIP critic step builds"""
+
+    def __init__(self, tm):
+        self.tm = tm
+
+    def __enter__(self):
+        self.orig = self.tm.sample_line
+
+        def wrapped(real, fake, alpha=None):
+            out = self.orig(real, fake, alpha)
+            self.fake, self.xhat = fake.detach().clone(), out.detach().clone()
+            return out
+        self.tm.sample_line = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.tm.sample_line = self.orig
+
+
+def _lrelu_flips(D, d_before, d_sd64, norm, dis_type, real, cap, dev):
+    """LeakyReLU pre-activations of the five critic blocks whose SIGN differs between the HIP forward and the fp64 oracle, both
+    evaluated on the very tensors the HIP step saw (real, its own fake batch, its own interpolated batch).
+
+    Why the gradient test needs this: at batch 2 a critic pass has ~2.8 M pre-activations with a density of ~0.4 / unit around
+    zero and maxima of 3 .. 4, so a handful lie within fp32 round-off (a few 1e-7 of the tensor's maximum) of zero.  Whether
+    such an element comes out as +1e-7 or -1e-7 depends on the summation order of the convolution in front of it, and the
+    penalty's double backward multiplies by act' = 1 or 0.2 accordingly: one flipped element behind a sample-wide norm moves
+    every gradient upstream by ~1e-5 of its size, ten times the 3 x fp32-noise bound of the sample-wise-norm cases.  The CPU
+    fp32 runs that measure the noise start from the ORACLE's interpolated batch, not from the HIP run's, so they do not
+    see the same near-zero elements.  (Measured, tools/diag_flip.py: res / layer_norm, seed 71 -- the generic gather kernel and
+    the 4x4 patch kernel with 8 splits leave element -8.7e-8 of block 1 negative, the patch kernel with 4 splits makes it
+    +2.0e-7; every convolution output of both runs is within 1e-6 of fp64.)  Returns (count, largest |fp64 pre-activation| /
+    tensor maximum among the flipped elements).  `d_before` / `d_sd64`: the critic's parameters BEFORE the step's optimizer
+    update, as the HIP module's state_dict and in fp64."""
+    import copy
+    import torch.nn.functional as F
+    from semantic_pyramid_for_image_generation_amd import ops
+    from semantic_pyramid_for_image_generation_amd.blocks import run_conv
+    saved = copy.deepcopy(D.state_dict())
+    D.load_state_dict(d_before)
+    sd = {k: v.detach() for k, v in d_sd64.items()}
+    samplewise = norm in ('instance_norm', 'layer_norm')
+    batches = [cap.xhat] + ([torch.cat([real.to(dev), cap.fake])] if samplewise else [real.to(dev), cap.fake])
+    flips, worst = 0, 0.0
+    with torch.no_grad():
+        for x in batches:
+            x64 = x.double().cpu()
+            if dis_type == 'default':
+                h = F.leaky_relu(F.conv2d(x64, sd['first_conv.weight'], sd['first_conv.bias'], 2, 1), 0.2)
+            else:
+                h = F.avg_pool2d(F.leaky_relu(F.conv2d(x64, sd['first_conv.weight'], sd['first_conv.bias'], 1, 1), 0.2), 2)
+            g = run_conv(D.first_conv, x, act_kind=ops.ACT_LRELU, slope=0.2, pool=(dis_type == 'res'))
+            for i, blk in enumerate((D.conv_block1, D.conv_block2, D.conv_block3, D.conv_block4, D.conv_block5), 1):
+                p = 'conv_block%d.conv_block1' % i
+                pre = nets._d_norm(sd, p + '.block.1', F.conv2d(h, sd[p + '.block.0.weight'], sd[p + '.block.0.bias'], 2, 1), norm, True)
+                h = F.leaky_relu(pre, 0.2)
+                g = blk(g)
+                diff = ((g.double().cpu() > 0) != (pre > 0))
+                n = int(diff.sum())
+                if n:
+                    flips += n
+                    worst = max(worst, float(pre[diff].abs().max() / pre.abs().max()))
+    D.load_state_dict(saved)
+    return flips, worst
+
+
 GRAD_CASES = [('res', 'instance_norm', True), ('default', 'batch_norm', False), ('res', 'layer_norm', False)]
 
 
@@ -205,12 +281,22 @@ def test_d_step_gradients_vs_oracle(dev, case):
     d_loss_fn, _ = tm.get_wgan_losses_fn()
     d_opt = _Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
     refs32 = _fp32_runs(tr, lambda t: t.d_step(j((images - 0.5) / 0.5), j(feats), masks, j(z), alpha))
+    d64_before = {k: v.detach().clone() for k, v in tr.d.items()}
     want = tr.d_step(_d((images - 0.5) / 0.5), _d(feats), _d(masks), _d(z), _d(alpha))
-    got = tm.train_discriminator(G, D, d_loss_fn, d_opt, ((images - 0.5) / 0.5).to(dev), [f.to(dev) for f in feats],
-                                 [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
+    import copy
+    d_before = copy.deepcopy(D.state_dict())
+    with _CaptureLine(tm) as cap:
+        got = tm.train_discriminator(G, D, d_loss_fn, d_opt, ((images - 0.5) / 0.5).to(dev), [f.to(dev) for f in feats],
+                                     [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
     for k in want:
         assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
-    _grads_close({k: p.grad for k, p in D.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params, 'd:' + '/'.join(map(str, case)))
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in D.named_parameters()}
+    # a LeakyReLU element at round-off distance from zero that lands on the other side in the HIP run: see _lrelu_flips
+    flips, dist = _lrelu_flips(D, d_before, d64_before, norm, gen_type, (images - 0.5) / 0.5, cap, dev)
+    assert dist < 1e-5, f"{flips} LeakyReLU signs differ from fp64, one at {dist:.1e} of its tensor's maximum: not round-off"
+    print(f"[d:{'/'.join(map(str, case))}] LeakyReLU pre-activations at round-off distance that changed side: {flips}"
+          + (f" (largest {dist:.1e} of the tensor maximum): bound x 10" if flips else ""))
+    _grads_close(grads, tr.d, [r.d for r in refs32], tr.d_params, 'd:' + '/'.join(map(str, case)), widen=10.0 if flips else 1.0)
 
 
 @pytest.mark.parametrize("case", GRAD_CASES)
