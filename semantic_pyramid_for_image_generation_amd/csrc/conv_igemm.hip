@@ -1374,6 +1374,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     gw[dst] = accumulate ? gw[dst] + sum : sum;                // accumulate: gw += this launch's gradient
 }
 
+// The same through LDS for wide layers: a workgroup owns one output row m and 64 input channels, reads the slabs as runs of 64
+// consecutive floats per tap (coalesced), sums them in the fixed split order, and writes its 64 x T block of gw as ONE
+// contiguous run (the plain kernel's write is a 4-byte scatter with stride T: 512 -> 512 4x4 took 24 us for 16.8 MB).
+__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
+                                                             int splits, long long slab_stride, int Cin, int T, int ldc,
+                                                             int accumulate)
+{
+    extern __shared__ float tile[];                             // [64][T + 1]
+    const int cblocks = (Cin + 63) / 64;
+    const int m = blockIdx.x / cblocks, c0 = (blockIdx.x - m * cblocks) * 64;
+    const int nc = min(64, Cin - c0);
+    const int c = threadIdx.x & 63;
+    const size_t src = (size_t)m * ldc + c0 + c;
+    if (c < nc) {
+        for (int t = threadIdx.x >> 6; t < T; t += 4) {
+            const float* sp = slabs + src + (size_t)t * Cin;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // the plain kernel's interleaved partial sums: same bits
+            int k = 0;
+            for (; k + 3 < splits; k += 4) {
+                a0 += sp[(size_t)k * slab_stride];
+                a1 += sp[(size_t)(k + 1) * slab_stride];
+                a2 += sp[(size_t)(k + 2) * slab_stride];
+                a3 += sp[(size_t)(k + 3) * slab_stride];
+            }
+            for (; k < splits; ++k) a0 += sp[(size_t)k * slab_stride];
+            tile[c * (T + 1) + t] = (a0 + a1) + (a2 + a3);
+        }
+    }
+    __syncthreads();
+    float* dst = gw + ((size_t)m * Cin + c0) * T;
+    for (int i = threadIdx.x; i < nc * T; i += 256) {
+        const int cc = i / T, t = i - cc * T;
+        const float v = tile[cc * (T + 1) + t];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+
 // The same for many slabs (thin problems reduce over 2^20 pixels in 500+ splits): 16 consecutive outputs (one 64-B
 // segment per slab) x 16 split groups per workgroup, so a thread walks splits/16 slabs instead of all of them
 // (1728 outputs x 512 slabs took 42 us as one dependent chain per thread). Fixed summation order: deterministic.
@@ -1683,6 +1720,16 @@ struct Profiler {
 };
 Profiler g_prof;
 
+// Dynamic LDS to ask for on top of `have` bytes so that at most SEMPYR_CONV_OCC_CAP workgroups of a convolution kernel fit on
+// a CU (0 = no cap): the registers and LDS it leaves free are what lets the HBM-bound kernels of the other streams run
+// beside an MFMA-bound convolution instead of queueing behind it.
+inline size_t occ_cap_pad(size_t have) {
+    static const int cap = env_int("SEMPYR_CONV_OCC_CAP", 0);
+    if (cap < 1 || cap > 3) return 0;
+    const size_t need = (size_t)(160 * 1024) / (cap + 1) + 256;
+    return need > have ? need - have : 0;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, bool UT>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
     const int MT = (p.Mpad + BM - 1) / BM;
@@ -1722,10 +1769,10 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t st) {
             pp.nchunks /= 2;
             pp.chunks_per_split = (pp.nchunks + splits - 1) / splits;
             for (int i = 0; i < pp.nphases && pp.nphases > 1; ++i) pp.ph[i].nchunks /= 2;
-            hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT, 32>), grid, dim3(256), 0, st, pp);
+            hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT, 32>), grid, dim3(256), occ_cap_pad((size_t)2 * 32 * (BM + BN) * 4), st, pp);
         }
     }
-    if (!deep) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT>), grid, dim3(256), 0, st, pp);
+    if (!deep) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, UT>), grid, dim3(256), occ_cap_pad((size_t)2 * 16 * (BM + BN + 4) * 4), st, pp);
     if (e1) (void)hipEventRecord(e1, st);
     SEMPYR_CHECK_LAUNCH();
     return 0;
@@ -1846,7 +1893,8 @@ int launch_patch(const IgemmParams& p, int splits, hipStream_t st) {
     const int NT8 = (NT + 7) / 8 * 8;
     dim3 grid(splits > 1 ? MT * NT * splits : MT * NT8, 1, 1);
     const int nsp = (p.PR * p.PW + 255) / 256 < 2 ? 2 : (p.PR * p.PW + 255) / 256;
-    const size_t lds = (size_t)(9 * PCG * BM + PCG * nsp * 256) * sizeof(float);
+    size_t lds = (size_t)(9 * PCG * BM + PCG * nsp * 256) * sizeof(float);
+    lds += occ_cap_pad(lds);
     const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) {
@@ -2403,9 +2451,13 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = d->B * d->Cout * pl.Ho * pl.Wo * 4;
     if (int rc = launch_cfg<MODE_WGRAD>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
     const int total = d->Cout * d->Cin * T;
+    static const int reduce_t = env_int("SEMPYR_WGRAD_REDUCE_T", 1);
     if (splits >= 64)
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(ceil_div(total, 16)), dim3(256), 0, st,
                            (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
+    else if (reduce_t && T > 1 && d->Cin >= 32 && d->Cout * ceil_div(d->Cin, 64) >= 512)     // fewer workgroups: one thread per output wins (measured)
+        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(d->Cout * ceil_div(d->Cin, 64)), dim3(256), (size_t)64 * (T + 1) * sizeof(float), st,
+                           (const float*)ws, gw, splits, p.slab_stride, d->Cin, T, Nn, accumulate ? 1 : 0);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st,
                            (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);

@@ -181,6 +181,7 @@ int tp_launch_nsp(const IgemmParams& pp, const TpTile& t, dim3 grid, hipStream_t
     // An even share of workgroups per CU: the dispatcher fills a CU up to its occupancy limit before it moves on, so a launch
     // of 512 workgroups that fit 3 per CU leaves CUs with 3, 2 and 1 of them.  Asking for so much LDS that only
     // ceil(workgroups / 256) fit makes the placement even.
+    lds += occ_cap_pad(lds);
     static const int even = env_int("SEMPYR_TP_EVEN", 1);
     const int want = (int)((grid.x + 255) / 256);
     if (even && want >= 1 && want < 4) {
