@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # SURVEY.md §8(d) algorithmic FLOPs (2 FLOP/MAC, reference's wasted work excluded), per sample:
 F_G, F_D, F_C = 19.053e9, 1.703e9, 4.738e9
 D_STEP_FLOPS = F_C + F_G + 12 * F_D            # 44.23 GFLOP / sample
@@ -139,6 +140,25 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def hbm_report(steps):
+    """Per HBM-bound kernel of the bracket that sempyr_profile_end just closed: launches, algorithmic bytes (4 B x
+    elements read once + written once, counted by the library at the launch site) and summed HIP-event duration."""
+    from semantic_pyramid_for_image_generation_amd import _lib
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib.sempyr_profile_hbm_report(buf, len(buf)), "sempyr_profile_hbm_report")
+    rows = []
+    for line in buf.value.decode().strip().splitlines()[1:]:
+        name, n, nbytes, ms = line.rsplit(',', 3)
+        n, nbytes, ms = int(n), float(nbytes), float(ms)
+        if ms <= 0:
+            continue
+        rows.append({"kernel": name, "launches_per_cycle": n / steps, "ms_per_cycle": ms / steps,
+                     "algorithmic_MB_per_launch": nbytes / n / 1e6, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
+                     "frac_of_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    rows.sort(key=lambda r: -r["ms_per_cycle"])
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -237,6 +257,10 @@ def main():
         barrier()
         el = time.perf_counter() - t1
         _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
+        hbm_path = os.environ.get("SEMPYR_HBM_DUMP")
+        if hbm_path:
+            with open(hbm_path, "w") as f:
+                json.dump({"steps": a.steps, "kernels": hbm_report(a.steps)}, f, indent=1)
         print(json.dumps({"profile_pass": True, "steps": a.steps, "ms_per_step_single_stream": 1e3 * el / a.steps,
                           "conv_launches": int(kl.value), "conv_ms_hip_events": kms.value, "conv_gflop_2MNK": kf.value * 1e-9}), flush=True)
         return
@@ -310,6 +334,7 @@ def main():
     # reports the cost.
     kms, kl, kf = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
     elapsed_instr = None
+    hbm_rows = []
     if timing:
         # single-stream for this pass: a kernel's event-to-event time is only its own duration when nothing else shares the GPU
         saved = (ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH)
@@ -322,6 +347,7 @@ def main():
         barrier()
         elapsed_instr = time.perf_counter() - t1
         _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
+        hbm_rows = hbm_report(a.steps)
         ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH = saved
         lp.use_graphs = saved_graphs
     if world > 1:
@@ -426,6 +452,17 @@ def main():
                                "flops_per_cycle_survey": cycle_flops, "flops_counted_2MNK_per_cycle": kf.value / a.steps,
                                "achieved_on_survey_flops": cycle_flops * a.steps / (kms.value * 1e-3) / 1e12,
                                "table": "profiles/r02_conv_family_table.csv (rocprofv3 kernel trace of the same single-stream pass)"}
+        if hbm_rows:
+            # the HBM-bound kernels of the same instrumented pass: every kernel with >= 0.2 ms per cycle, the three furthest
+            # below the ~8 TB/s peak first (tensors of <= 268 MB partly live in the 256 MB Infinity Cache between producer and
+            # consumer, so some rates exceed what HBM alone gives; tiny finalize kernels are latency-, not bandwidth-bound)
+            big = [r for r in hbm_rows if r["ms_per_cycle"] >= 0.2]
+            out["hbm"] = {"peak_GBps": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "bytes": "algorithmic: 4 B x (elements read once + written once) per launch, counted at the launch site",
+                          "worst_three": sorted(big, key=lambda r: r["frac_of_peak"])[:3],
+                          "kernels_over_0.2ms_per_cycle": big,
+                          "other_kernels_ms_per_cycle": sum(r["ms_per_cycle"] for r in hbm_rows),
+                          "table": "profiles/r03_hbm_kernels.json (rocprofv3 durations of the same single-stream pass)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, a.use_diversity_loss)
         print(json.dumps(out), flush=True)

@@ -419,6 +419,10 @@ int sempyr_profile_begin(int max_launches);
 /* launches the do-nothing kernel `sempyr_marker_kernel` on `stream`: brackets a region in a rocprofv3 kernel trace */
 int sempyr_profile_marker(int tag, void* stream);
 int sempyr_profile_end(double* kernel_ms, int64_t* launches, double* flops);
+/* After sempyr_profile_end: per HBM-bound kernel that ran inside the bracket, one CSV line "kernel,launches,algorithmic_bytes,ms"
+ * (algorithmic bytes per SURVEY.md 8d: 4 B x elements read once + written once; ms = summed HIP-event durations on the launch
+ * streams).  No counterpart in the reference: measurement only (bench.py's `hbm` block, profiles/<round>_hbm_kernels.json). */
+int sempyr_profile_hbm_report(char* out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,7 @@ SIGNATURES = {
     "sempyr_profile_begin": [c_int],
     "sempyr_profile_marker": [c_int, _P],
     "sempyr_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
+    "sempyr_profile_hbm_report": [ctypes.c_char_p, ctypes.c_int64],
 }
 
 

@@ -105,6 +105,9 @@ static int adam_launch(const sempyr_adam_tensor* tensors, int n_tensors, int64_t
         }
         if (chunks >= (1ll << 31)) SEMPYR_FAIL("adam: too many elements for one launch");
         a.first_chunk[n] = (int)chunks; a.n = n;
+        double numel = 0.0;
+        for (int i = 0; i < n; ++i) numel += (double)a.numel[i];
+        HbmScope hs("adam_kernel", 28.0 * numel, (hipStream_t)stream);
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
         SEMPYR_CHECK_LAUNCH();
     }

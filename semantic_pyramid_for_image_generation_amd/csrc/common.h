@@ -15,6 +15,19 @@ void sempyr_set_error(const char* fmt, ...);
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Measurement only (bench.py's roofline leg, never enabled by the product path): while sempyr_profile_begin/end bracket a
+// region, an HbmScope around the launch of an HBM-bound kernel records a HIP event pair on the launch stream and the launch's
+// ALGORITHMIC bytes (4 B x elements read once + written once).  sempyr_profile_hbm_report lists, per kernel name,
+// launches, bytes and summed duration.  Off: one relaxed load and a branch.
+struct HbmScope {
+    int slot;
+    hipStream_t st;
+    HbmScope(const char* name, double bytes, hipStream_t stream);
+    ~HbmScope();
+};
+void sempyr_hbm_profile_begin(int max_launches);
+void sempyr_hbm_profile_end();
+
 // wave64 sum reduction (all lanes get the result)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

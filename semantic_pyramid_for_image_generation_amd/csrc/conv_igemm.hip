@@ -2147,6 +2147,7 @@ extern "C" int sempyr_conv2d_pack_weights_many(const sempyr_pack_item* items, in
     auto flush = [&]() -> int {
         if (n == 0) return 0;
         a.first_block[n] = (int)blocks; a.n = n;
+        HbmScope hs("pack_weights_many_kernel", 2048.0 * (double)blocks, (hipStream_t)stream);
         hipLaunchKernelGGL(pack_weights_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
         SEMPYR_CHECK_LAUNCH();
         n = 0; blocks = 0;
@@ -2178,6 +2179,7 @@ static int run_splitk_reduce(const float* slabs, float* out, const float* bias, 
 {
     // float4 path only when every slab start (k * numel floats) stays 16-byte aligned
     const bool res_ok = res_w > 0 ? (res_w % 4 == 0 && ((uintptr_t)res & 7) == 0) : (((uintptr_t)res & 15) == 0);
+    HbmScope hs("splitk_reduce_kernel", 4.0 * (double)numel * (splits + 1.0 + (res ? (res_w > 0 ? 0.25 : 1.0) : 0.0)), st);
     if (numel % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0 && res_ok) {
         const int total4 = (int)(numel / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st,
@@ -2452,6 +2454,7 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     if (int rc = launch_cfg<MODE_WGRAD>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
     const int total = d->Cout * d->Cin * T;
     static const int reduce_t = env_int("SEMPYR_WGRAD_REDUCE_T", 1);
+    HbmScope hs("wgrad_reduce_kernel (all forms)", 4.0 * (double)total * (splits + 1.0 + (accumulate ? 1.0 : 0.0)), st);
     if (splits >= 64)
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(ceil_div(total, 16)), dim3(256), 0, st,
                            (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
@@ -2489,11 +2492,13 @@ extern "C" int sempyr_profile_begin(int max_launches)
         g_prof.events.push_back(e);
     }
     g_prof.used = 0; g_prof.flops = 0.0; g_prof.recs.clear(); g_prof.on = true;
+    sempyr_hbm_profile_begin(max_launches);
     return 0;
 }
 
 extern "C" int sempyr_profile_end(double* kernel_ms, int64_t* launches, double* flops)
 {
+    sempyr_hbm_profile_end();
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = false;
     double ms = 0.0;

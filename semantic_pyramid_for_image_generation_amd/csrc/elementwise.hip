@@ -508,6 +508,7 @@ static int affine_act_launch(const float* x, const float* sub_row, const float* 
     const long long total = (long long)rows * len;
     const int vec = (len % 4 == 0) && aligned16(x) && aligned16(y) &&
                     (!res || (res_w > 0 ? (res_w % 4 == 0 && (((uintptr_t)res) & 7) == 0) : aligned16(res)));
+    HbmScope hs("affine_act_kernel", 4.0 * total * (2.0 + (res ? (res_w > 0 ? 0.25 : 1.0) : 0.0)), (hipStream_t)stream);
     LAUNCH_1D(affine_act_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, sub_row, scale_row, shift_row, res,
               rsub_row, rscale_row, rshift_row, y, total, len, vec, act, slope, res_w);
     return 0;
@@ -537,6 +538,7 @@ extern "C" int sempyr_affine_act_bwd(const float* gy, const float* y, const floa
     if (act < 0 || act > 3) SEMPYR_FAIL("affine_act_bwd: bad activation %d", act);
     const long long total = (long long)rows * len;
     const int vec = (len % 4 == 0) && aligned16(gy) && (!y || aligned16(y)) && (!gx || aligned16(gx)) && (!gres || aligned16(gres));
+    HbmScope hs("affine_act_bwd_kernel", 4.0 * total * (1.0 + (y ? 1 : 0) + (gx ? 1 : 0) + (gres ? 1 : 0)), (hipStream_t)stream);
     LAUNCH_1D(affine_act_bwd_kernel, vec ? total / 4 : total, (hipStream_t)stream, gy, y, scale_row, gx, gres, total, len, vec, act, slope);
     return 0;
 }
@@ -559,6 +561,7 @@ extern "C" int sempyr_mul(const float* a, const float* b, float* y, int64_t n, v
 {
     if (!a || !b || !y || n < 1) SEMPYR_FAIL("mul: bad arguments");
     const int vec = (n % 4 == 0) && aligned16(a) && aligned16(b) && aligned16(y);
+    HbmScope hs("mul_kernel", 12.0 * n, (hipStream_t)stream);
     LAUNCH_1D(mul_kernel, vec ? n / 4 : n, (hipStream_t)stream, a, b, y, (long long)n, vec);
     return 0;
 }
@@ -577,6 +580,7 @@ extern "C" int sempyr_lerp_rows(const float* real, const float* fake, const floa
     if (!real || !fake || !alpha_row || !out || rows < 1 || len < 1) SEMPYR_FAIL("lerp_rows: bad arguments");
     const long long total = (long long)rows * len;
     const int vec = (len % 4 == 0) && aligned16(real) && aligned16(fake) && aligned16(out);
+    HbmScope hs("lerp_rows_kernel", 12.0 * total, (hipStream_t)stream);
     LAUNCH_1D(lerp_rows_kernel, vec ? total / 4 : total, (hipStream_t)stream, real, fake, alpha_row, out, total, len, vec);
     return 0;
 }
@@ -587,6 +591,7 @@ extern "C" int sempyr_normalize(const float* x, const float* mean_c, const float
     if (!x || !std_c || !y || (!backward && !mean_c) || N < 1 || C < 1 || HW < 1) SEMPYR_FAIL("normalize: bad arguments");
     const long long total = (long long)N * C * HW;
     const int vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+    HbmScope hs("normalize_kernel", 8.0 * total, (hipStream_t)stream);
     LAUNCH_1D(normalize_kernel, vec ? total / 4 : total, (hipStream_t)stream, x, mean_c, std_c, y, total, C, HW, vec, backward ? 1 : 0);
     return 0;
 }
@@ -601,6 +606,7 @@ extern "C" int sempyr_pool2_down(const float* x, const float* yref, const uint32
     if (act < 0 || act > 3) SEMPYR_FAIL("pool2_down: bad activation %d", act);
     const long long total = (long long)rows * (H / 2) * (W / 2);
     if ((W & 3) == 0 && ((((uintptr_t)x | (uintptr_t)yref) & 15) == 0) && (((uintptr_t)y & 7) == 0)) {
+        HbmScope hs("pool2_down_v2_kernel", 4.0 * total * (5.0 + (yref ? 4.0 : act_bits ? 0.125 : 0.0)), (hipStream_t)stream);
         LAUNCH_1D(pool2_down_v2_kernel, total / 2, (hipStream_t)stream, x, yref, y, total / 2, H / 2, W / 4, scale, act, slope,
                   (const unsigned char*)act_bits);
         return 0;
@@ -636,6 +642,7 @@ extern "C" int sempyr_maxpool3s2_fwd(const float* x, float* y, int32_t* idx, int
     if (!x || !y || !idx || rows < 1 || H < 1 || W < 1) SEMPYR_FAIL("maxpool3s2_fwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)rows * Ho * Wo;
+    HbmScope hs("maxpool3s2_fwd_kernel", 4.0 * ((double)rows * H * W + 2.0 * total), (hipStream_t)stream);
     LAUNCH_1D(maxpool3s2_fwd_kernel, total, (hipStream_t)stream, x, y, idx, total, H, W, Ho, Wo);
     return 0;
 }
@@ -645,6 +652,7 @@ extern "C" int sempyr_maxpool3s2_bwd(const float* gy, const int32_t* idx, float*
     if (!gy || !gx || !idx || rows < 1 || H < 1 || W < 1) SEMPYR_FAIL("maxpool3s2_bwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)rows * H * W;
+    HbmScope hs("maxpool3s2_bwd_kernel", 4.0 * ((double)total + 2.0 * rows * Ho * Wo), (hipStream_t)stream);
     LAUNCH_1D(maxpool3s2_bwd_kernel, total, (hipStream_t)stream, gy, idx, gx, total, H, W, Ho, Wo);
     return 0;
 }

@@ -894,10 +894,14 @@ extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW,
     const int rows = N * C;
     const int vec = (HW % 4 == 0) && aligned16(x);
     float* rmean = scratch; float* rm2 = scratch + rows;
-    if (HW >= 2048) hipLaunchKernelGGL(row_moments_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, HW, vec, rmean, rm2);
-    else hipLaunchKernelGGL(row_moments_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, HW, vec, rmean, rm2);
+    {
+        HbmScope hs(HW >= 2048 ? "row_moments_kernel<256>" : "row_moments_kernel<64>", 4.0 * rows * HW, st);
+        if (HW >= 2048) hipLaunchKernelGGL(row_moments_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, HW, vec, rmean, rm2);
+        else hipLaunchKernelGGL(row_moments_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, HW, vec, rmean, rm2);
+    }
     SEMPYR_CHECK_LAUNCH();
     const int ng = num_groups(kind, N, C);
+    HbmScope hs_fin("norm_finalize_kernel", 4.0 * 6.0 * rows, st);
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div((long long)ng * FIN_LPG, 256)), dim3(256), 0, st, kind, rmean, rm2, N, C, HW, eps,
                        gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, (float)rep,
                        rowbuf, rowbuf + rows, rowbuf + 2 * rows, rowbuf + 3 * rows);
@@ -916,6 +920,7 @@ extern "C" int sempyr_bn_stats_from_tiles(const float* tile_stats, int N, int C,
     if (rep < 1) SEMPYR_FAIL("bn_stats_from_tiles: replication factor %d", rep);
     if (((uintptr_t)tile_stats & 7)) SEMPYR_FAIL("bn_stats_from_tiles: the statistics buffer must be 8-byte aligned");
     const int rows = N * C;
+    HbmScope hs("bn_tile_finalize_kernel", 8.0 * rows * (HW / granule) + 16.0 * rows, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_tile_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float2*>(tile_stats), N, C, HW / granule, granule, eps, gamma, beta,
                        running_mean, running_var, (long long*)num_batches_tracked, momentum, (float)rep,
@@ -936,6 +941,7 @@ extern "C" int sempyr_norm_fwd(int kind, const float* x, int N, int C, int HW, f
         hipStream_t st = (hipStream_t)stream;
         const int vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
         bool done = false;
+        HbmScope hs("instnorm_fwd_kernel", 8.0 * rows * HW, st);
         if (vec && HW >= 2048 && HW % 1024 == 0) done = launch_instnorm_fwd_reg<256>(HW / 1024, dim3(rows), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
         else if (vec && HW < 2048 && HW % 256 == 0) done = launch_instnorm_fwd_reg<64>(HW / 256, dim3(ceil_div(rows, 4)), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
         else if (vec && HW == 64) done = launch_instnorm_fwd_reg<16>(1, dim3(ceil_div(rows, 16)), st, x, rows, C, eps, gamma, beta, act, slope, y, rowbuf);
@@ -977,6 +983,7 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     float* sums = scratch;
     if (kind == SEMPYR_NORM_INSTANCE && HW <= INST_FUSED_MAX_LEN && inst_fused_on()) {
         bool done = false;
+        HbmScope* hs = new HbmScope("instnorm_bwd_kernel", 16.0 * rows * HW, st);
         if (vec && HW >= 2048 && HW % 1024 == 0) done = launch_instnorm_bwd_reg<256>(HW / 1024, dim3(rows), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
         else if (vec && HW < 2048 && HW % 256 == 0) done = launch_instnorm_bwd_reg<64>(HW / 256, dim3(ceil_div(rows, 4)), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
         else if (vec && HW == 64) done = launch_instnorm_bwd_reg<16>(1, dim3(ceil_div(rows, 16)), st, gy, y, x, gamma, mean_row, rstd_row, rows, C, act, slope, gx, sums);
@@ -985,16 +992,21 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
         if (HW >= 2048) hipLaunchKernelGGL(instnorm_bwd_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);
         else hipLaunchKernelGGL(instnorm_bwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, gamma, mean_row, rstd_row, rows, C, HW, vec, act, slope, gx, sums);
         }
+        delete hs;
         SEMPYR_CHECK_LAUNCH();
         if (ggamma || gbeta) {
+            HbmScope hc("norm_bwd_channel_kernel", 4.0 * (5.0 * rows + 2.0 * C), st);
             hipLaunchKernelGGL(norm_bwd_channel_kernel, dim3(ceil_div((long long)C * FIN_LPG, 256)), dim3(256), 0, st, sums, rstd_row, N, C, HW, ggamma, gbeta);
             SEMPYR_CHECK_LAUNCH();
         }
         return 0;
     }
     float* cA = scratch + 4 * rows; float* cB = scratch + 5 * rows; float* cC = scratch + 6 * rows;
-    if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
-    else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+    {
+        HbmScope hs(HW >= 2048 ? "norm_bwd_rowsums_kernel<256>" : "norm_bwd_rowsums_kernel<64>", 4.0 * rows * HW * (act == SEMPYR_ACT_NONE ? 2.0 : 3.0), st);
+        if (HW >= 2048) hipLaunchKernelGGL(norm_bwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+        else hipLaunchKernelGGL(norm_bwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+    }
     SEMPYR_CHECK_LAUNCH();
     const int nthreads = (num_groups(kind, N, C) + C) * FIN_LPG;
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(nthreads, 256)), dim3(256), 0, st, kind, sums, N, C, HW, gamma,
@@ -1002,6 +1014,7 @@ extern "C" int sempyr_norm_bwd(int kind, const float* gy, const float* y, const 
     SEMPYR_CHECK_LAUNCH();
     const long long total = (long long)rows * HW;
     const long long nthr = vec ? total / 4 : total;
+    HbmScope hs_apply("norm_bwd_apply_kernel", 4.0 * total * (act == SEMPYR_ACT_NONE ? 3.0 : 4.0), st);
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, gy, y, x, mean_row, cA, cB, cC, total, HW, vec, act, slope, gx);
     SEMPYR_CHECK_LAUNCH();
     return 0;
@@ -1020,8 +1033,11 @@ extern "C" int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, co
     const int vec = (HW % 4 == 0) && aligned16(u) && aligned16(gy) && aligned16(x) && aligned16(g_gy) && aligned16(g_x) &&
                     (act == SEMPYR_ACT_NONE || aligned16(y));
     float* sums = scratch; float* coef = scratch + 9 * rows;
-    if (HW >= 2048) hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
-    else hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+    {
+        HbmScope hs(HW >= 2048 ? "norm_bwdbwd_rowsums_kernel<256>" : "norm_bwdbwd_rowsums_kernel<64>", 4.0 * rows * HW * (act == SEMPYR_ACT_NONE ? 3.0 : 4.0), st);
+        if (HW >= 2048) hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<256>, dim3(rows), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+        else hipLaunchKernelGGL(norm_bwdbwd_rowsums_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, u, gy, y, x, mean_row, rows, HW, vec, act, slope, sums);
+    }
     SEMPYR_CHECK_LAUNCH();
     hipLaunchKernelGGL(norm_bwdbwd_finalize_kernel, dim3(ceil_div((long long)num_groups(kind, N, C) * FIN_LPG, 256)), dim3(256), 0, st,
                        kind, sums, N, C, HW, gamma, rstd_row, coef);
@@ -1032,6 +1048,7 @@ extern "C" int sempyr_norm_bwd_bwd(int kind, const float* u, const float* gy, co
     }
     const long long total = (long long)rows * HW;
     const long long nthr = vec ? total / 4 : total;
+    HbmScope hs_apply("norm_bwdbwd_apply_kernel", 4.0 * total * (act == SEMPYR_ACT_NONE ? 5.0 : 6.0), st);
     hipLaunchKernelGGL(norm_bwdbwd_apply_kernel, dim3(ceil_div(nthr, 256)), dim3(256), 0, st, u, gy, y, x, mean_row, coef, rows, total, HW, vec, act, slope, g_gy, g_x);
     SEMPYR_CHECK_LAUNCH();
     return 0;

@@ -325,9 +325,13 @@ extern "C" int sempyr_channel_sum(const float* x, int N, int C, int HW, float sc
     hipStream_t st = (hipStream_t)stream;
     const int rows = N * C;
     const int vec = (HW % 4 == 0) && aligned16(x);
-    if (HW >= 2048) hipLaunchKernelGGL(row_sum_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, HW, vec, scratch);
-    else hipLaunchKernelGGL(row_sum_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, HW, vec, scratch);
+    {
+        HbmScope hs(HW >= 2048 ? "row_sum_kernel<256>" : "row_sum_kernel<64>", 4.0 * rows * HW, st);
+        if (HW >= 2048) hipLaunchKernelGGL(row_sum_kernel<256>, dim3(rows), dim3(256), 0, st, x, rows, HW, vec, scratch);
+        else hipLaunchKernelGGL(row_sum_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, HW, vec, scratch);
+    }
     SEMPYR_CHECK_LAUNCH();
+    HbmScope hs_fold("channel_fold_kernel", 4.0 * (rows + C), st);
     hipLaunchKernelGGL(channel_fold_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, N, C, scale, out, accumulate ? 1 : 0);
     SEMPYR_CHECK_LAUNCH();
     return 0;
