@@ -103,3 +103,64 @@ def test_flat_gradient_allreduce_world2():
     for (l0, s0), (l1, s1) in zip(res[0][1], res[1][1]):
         assert np.allclose(s0, l0 + l1, atol=1e-7) and np.array_equal(s0, s1)      # the SUM; Adam's grad_scale = 1/N makes it the mean
         assert np.abs(l0 - l1).max() > 1e-4
+
+
+def _worker_product(rank, world, port, q):
+    """the PRODUCT critic's flat gradient buffer and its bucketed exchange: three gradient contributions per weight and step, in
+    the order a backward pass issues them (last layer first), announced through the hook the weight-gradient path calls"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from semantic_pyramid_for_image_generation_amd import parallel
+    from semantic_pyramid_for_image_generation_amd.discriminator import Discriminator
+    torch.manual_seed(0)
+    D = Discriminator('instance_norm', 'res'); D.init_weights()
+    parallel.broadcast_module(D)
+    fg = parallel.flatten_grads(D, bucket_bytes=4 << 20)
+    assert len(fg.buckets) >= 2 and fg.flat.numel() >= 7026753
+    weights = [p for p in D.parameters() if p.dim() >= 2][::-1]
+    small = [p for p in D.parameters() if p.dim() < 2]
+    out = []
+    shadow = torch.zeros_like(fg.flat)               # this rank's own gradient (a bucket may be summed in place before the pass ends)
+    where = {id(p): (p.grad.data_ptr() - fg.flat.data_ptr()) // 4 for p in D.parameters()}
+    for step in range(4):
+        g = torch.Generator().manual_seed(100 * rank + step)
+        parallel.zero_gradients(D)
+        shadow.zero_()
+
+        def contribute(p):
+            r = torch.randn(p.shape, generator=g)
+            p.grad.add_(r)
+            shadow[where[id(p)]:where[id(p)] + p.numel()].add_(r.reshape(-1))
+        for rep in range(3):                         # logit pass + both chains of the penalty's double backward
+            for p in weights:
+                contribute(p)
+                parallel._on_grad_issued(p)
+        for p in small:
+            contribute(p)
+        local = shadow.clone()
+        parallel.sync_gradients(D)
+        out.append((float(local.double().sum()), float(local.abs().max()), fg.flat[::4099].clone().numpy(), local[::4099].numpy()))
+        fg.flat.zero_()
+    q.put((rank, out, dict(fg.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_product_critic_bucketed_exchange_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_product, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    import numpy as np
+    (_, o0, st0), (_, o1, st1) = res
+    for (s0, m0, f0, l0), (s1, m1, f1, l1) in zip(o0, o1):
+        assert np.allclose(f0, l0 + l1, atol=1e-5) and np.array_equal(f0, f1)       # the SUM on both ranks, bit-identical
+        assert np.abs(l0 - l1).max() > 1e-2
+    # the contribution counts are learned from two identical steps; from then on the buckets go out from inside the pass
+    assert st0 == st1 and st0["early"] >= len(res) and st0["late"] > 0 and st0["steps"] == 4
