@@ -666,6 +666,9 @@ class _ConvFwd(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, plan, act_kind=ACT_NONE, slope=0.0, pool=False, stats=0):
+        # graph_only_input_grad(x): the gradient with respect to x is wanted inside a create_graph pass only (the gradient
+        # penalty's interpolated batch); a plain backward pass through this convolution then skips it
+        ctx.dx_graph_only = getattr(x, '_sempyr_dx_graph_only', False)
         x = _req(x, "conv input"); w = _req(w, "conv weight")
         if bias is not None:
             bias = _req(bias, "conv bias")
@@ -703,11 +706,12 @@ class _ConvFwd(Function):
         gy = gy.contiguous()
         want_w = ctx.needs_input_grad[1] and not _INPUT_GRADS_ONLY
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not _INPUT_GRADS_ONLY
+        want_x = ctx.needs_input_grad[0] and not (ctx.dx_graph_only and not torch.is_grad_enabled())
         bsrc = None               # what the bias gradient is the channel sum of (default: gy itself)
         if ctx.pool:
             h, wd = gy.shape[2], gy.shape[3]
             yref, bits = (None, y) if ctx.bits else (y, None)
-            if ctx.bits and ctx.needs_input_grad[0] and not (want_w or want_b):
+            if ctx.bits and want_x and not (want_w or want_b):
                 # input gradient only (gradient penalty's inner pass, generator step): one Function whose own backward
                 # (the penalty's double backward) is a single fused launch
                 return _apply(_StemInputGrad, gy, w, bits, plan, *ctx.act), None, None, None, None, None, None, None
@@ -717,7 +721,7 @@ class _ConvFwd(Function):
                 slope = ctx.act[1] if ctx.act[0] == ACT_LRELU else 0.0
                 gy = _req(gy, "grad")
                 gw, gb = _stem_param_grads(gy, bits, slope, x, plan, w, bias, want_b)
-                gx = _raw_stem_dgrad(plan, gy, bits, slope, w) if ctx.needs_input_grad[0] else None
+                gx = _raw_stem_dgrad(plan, gy, bits, slope, w) if want_x else None
                 return gx, gw, gb, None, None, None, None, None
             if want_b and not torch.is_grad_enabled() and (h * wd) % 512 == 0 and wd % 2 == 0 and y.data_ptr() % 16 == 0:
                 # the un-pool pass also emits per-row partial sums: the bias gradient needs no second pass over the
@@ -737,7 +741,7 @@ class _ConvFwd(Function):
                     gw = _apply(_ConvWgrad, gy, x, plan)
                 if want_b:
                     gb = _bias_grad(gy if bsrc is None else bsrc)
-        if ctx.needs_input_grad[0]:
+        if want_x:
             gx = _conv_input_grad(gy, w, plan)
         return gx, gw, gb, None, None, None, None, None
 
@@ -848,6 +852,15 @@ class _ConvWgrad(Function):
         if ctx.needs_input_grad[1]:
             g_x = _conv_input_grad(gy, ggw, plan)
         return g_gy, g_x, None
+
+
+def graph_only_input_grad(x):
+    """Mark a leaf that requires grad as differentiated inside `torch.autograd.grad(..., create_graph=True)` ONLY: a plain
+    backward pass then does not compute the gradient with respect to it.  The WGAN-GP penalty (train_model.py:69-76) makes
+    its interpolated batch such a leaf; the reference's `loss.backward()` goes on to compute d loss / d x-hat through the
+    critic's first convolution and throws it away.  Parameter gradients do not depend on it."""
+    x._sempyr_dx_graph_only = True
+    return x
 
 
 def conv2d(x, w, bias=None, stride=1, padding=0, upsample=False, act_kind=ACT_NONE, slope=0.0, pool=False, stats=False):

@@ -144,6 +144,7 @@ def gradient_penalty(f, real, fake, alpha=None):
     Only the input gradient is wanted, so parameter gradients are skipped in this inner pass."""
     x = sample_line(real, fake, alpha).detach()
     x.requires_grad = True
+    ops.graph_only_input_grad(x)      # d loss / d x is never read: the plain backward pass stops at the critic's first convolution
     pred = f(x)
     with ops.input_grads_only():
         grad = torch.autograd.grad(pred, x, grad_outputs=ops.full_like(pred, 1.0), create_graph=True)[0]
