@@ -88,11 +88,14 @@ def cpu_baseline(batch, diversity):
         t0 = time.time(); tr.g_step(feats, masks, 3, z, z2 if diversity else None); t_g = time.time() - t0
         return t_clf, t_d, t_g
     one(2, False)                                   # warm-up: thread pools, oneDNN primitive caches, allocator
-    t_clf, t_d, t_g = one(batch, True)
+    reps = [one(batch, True) for _ in range(3)]     # three timed repetitions (~8 s each on 16 cores): the median is reported
+    med = lambda i: sorted(r[i] for r in reps)[1]
+    t_clf, t_d, t_g = med(0), med(1), med(2)
     cycle = 5 * (t_clf + t_d) + t_g
     return {"value": 5.0 / cycle, "unit": "iters/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
-            "sample": f"oracle (torch-CPU restatement) at batch {batch}, after a batch-2 warm-up: 1 classifier pass {t_clf:.2f}s + "
-                      f"1 D step {t_d:.2f}s + 1 G step {t_g:.2f}s, combined as 5*(clf+D)+G per cycle",
+            "sample": f"oracle (torch-CPU restatement) at batch {batch}, after a batch-2 warm-up, medians of 3 repetitions: 1 classifier "
+                      f"pass {t_clf:.2f}s + 1 D step {t_d:.2f}s + 1 G step {t_g:.2f}s, combined as 5*(clf+D)+G per cycle",
+            "repetitions": [{"clf_s": round(r[0], 3), "d_step_s": round(r[1], 3), "g_step_s": round(r[2], 3)} for r in reps],
             "torch": torch.__version__}
 
 
@@ -111,14 +114,16 @@ def cpu_baseline_eval():
         masks = [torch.ones_like(f) for f in feats]
         z = torch.randn(8, 128, 1, 1)
         nets.generator_forward(gsd, 'res', z[:2], [f[:2] for f in feats], [m[:2] for m in masks], False)        # warm-up
-        t0 = time.time()
-        for _ in range(2):
+        ts = []
+        for _ in range(5):
+            t0 = time.time()
             nets.generator_forward(gsd, 'res', z, feats, masks, False)
-        t_g = (time.time() - t0) / 2
+            ts.append(time.time() - t0)
+        t_g = sorted(ts)[2]
     total = t_clf + 16 * t_g
     return {"value": 128.0 / total, "unit": "images/s", "cores": _cpu_threads(), "os_cpu_count": os.cpu_count(), "kind": "port",
-            "sample": f"oracle at batch 8: 1 classifier pass {t_clf:.2f}s + 2 generator forwards ({t_g:.2f}s each), "
-                      "extrapolated to 16 forwards = 128 images"}
+            "sample": f"oracle at batch 8: 1 classifier pass {t_clf:.2f}s + the median of 5 generator forwards ({t_g:.2f}s), "
+                      "16 forwards = 128 images per source batch"}
 
 
 def launch_ranks(n, argv):
@@ -426,14 +431,14 @@ def main():
                 out["eval_cpu_baseline"] = cpu_baseline_eval()
         if timing and kl.value > 0:
             # algorithmic FLOPs of the launches that ran (2*M*N*K on unpadded dims, summed by the library).  SURVEY 8(d)'s
-            # per-cycle figure is quoted beside it; the executed count is ~17 % lower (3857 vs 4659 GFLOP per cycle in round 2)
+            # per-cycle figure is quoted beside it; the executed count is ~18 % lower (3817 vs 4659 GFLOP per cycle)
             # because classifier layers and feature-branch convolutions behind all-zero masks (levels at or above the selected
             # layer, quirk Q2) are not executed, and the 1x1 skip convolutions run before the upsample.
             achieved = kf.value / (kms.value * 1e-3) / 1e12
             # HBM-side bytes per launch: PMC passes cannot run inside this process; the committed per-kernel summary of the
-            # dominant family (tools/pmc_top3.sh -> profiles/r02_top3_traffic.json) is quoted; None if absent.
+            # dominant family (tools/pmc_top3.sh -> profiles/r03_top3_traffic.json) is quoted; None if absent.
             traffic = traffic_note = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_top3_traffic.json")
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_top3_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     top = json.load(f)["families"][0]
@@ -441,7 +446,7 @@ def main():
                 traffic_note = f"{top['name']}: measured {traffic / 1e6:.0f} MB vs algorithmic {top['algorithmic_bytes'] / 1e6:.0f} MB per launch"
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_of": traffic_note,
-                               "kernel": "implicit-GEMM conv kernels on fp32 v_mfma_f32_32x32x2_f32 (igemm_kernel fwd/dgrad/wgrad, patch3x3_kernel; incl. the VALU RGB-head launches)",
+                               "kernel": "implicit-GEMM conv kernels on fp32 v_mfma_f32_32x32x2_f32 (igemm_kernel fwd/dgrad/wgrad, patch3x3_kernel, tpatch_kernel; incl. the VALU RGB-head launches)",
                                "launches": int(kl.value), "avg_launch_us": 1000.0 * kms.value / kl.value,
                                "kernel_ms_total": kms.value, "kernel_time_share": kms.value * 1e-3 / elapsed_instr,
                                "instrumented_ms_per_step": 1000.0 * elapsed_instr / a.steps,
@@ -451,7 +456,7 @@ def main():
                                        "no events)",
                                "flops_per_cycle_survey": cycle_flops, "flops_counted_2MNK_per_cycle": kf.value / a.steps,
                                "achieved_on_survey_flops": cycle_flops * a.steps / (kms.value * 1e-3) / 1e12,
-                               "table": "profiles/r02_conv_family_table.csv (rocprofv3 kernel trace of the same single-stream pass)"}
+                               "table": "profiles/r03_conv_family_table.csv (rocprofv3 kernel trace of the same single-stream pass)"}
         if hbm_rows:
             # the HBM-bound kernels of the same instrumented pass: every kernel with >= 0.2 ms per cycle, the three furthest
             # below the ~8 TB/s peak first (tensors of <= 268 MB partly live in the 256 MB Infinity Cache between producer and

@@ -1,10 +1,10 @@
-"""gpurun_out/pmc_top3/* -> gpurun_out/r02_top3_traffic.json (copy to profiles/): per-launch HBM-side bytes of the top three
+"""gpurun_out/pmc_top3/* -> gpurun_out/r03_top3_traffic.json (copy to profiles/): per-launch HBM-side bytes of the top
 conv families next to their algorithmic bytes.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE tallies
 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section), so it is doubled; dword gathers are not a calibrated access width, so
 the read figure is an estimate.  Infinity-Cache hits are counted as traffic."""
 import csv, glob, json, os
 O = 'gpurun_out/pmc_top3'
-CONV = ('igemm_kernel', 'patch3x3_kernel')
+CONV = ('igemm_kernel', 'patch3x3_kernel', 'tpatch_kernel')
 fams = []
 for line in open(os.path.join(O, 'families.txt')):
     i, name, mode, B, Cin, H, W, Cout, k, s, p, ups = line.split()
@@ -25,5 +25,5 @@ for line in open(os.path.join(O, 'families.txt')):
                  'traffic_bytes_per_launch': fetch + write, 'traffic_over_algorithmic': (fetch + write) / alg})
 out = {'families': fams, 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/one_conv.py (3 launches of the '
        'conv per run, averaged); KiB -> bytes; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B)'}
-json.dump(out, open('gpurun_out/r02_top3_traffic.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/r03_top3_traffic.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
