@@ -182,7 +182,7 @@ int tp_launch_nsp(const IgemmParams& pp, const TpTile& t, dim3 grid, hipStream_t
     // of 512 workgroups that fit 3 per CU leaves CUs with 3, 2 and 1 of them.  Asking for so much LDS that only
     // ceil(workgroups / 256) fit makes the placement even.
     lds += occ_cap_pad(lds);
-    static const int even = env_int("SEMPYR_TP_EVEN", 1);
+    static const int even = env_int("SEMPYR_TP_EVEN", 0);      // measured: no effect on any critic shape (4 A/B runs), off
     const int want = (int)((grid.x + 255) / 256);
     if (even && want >= 1 && want < 4) {
         const size_t pad = (size_t)(160 * 1024) / (want + 1) + 256;
