@@ -462,9 +462,13 @@ def main():
             # below the ~8 TB/s peak first (tensors of <= 268 MB partly live in the 256 MB Infinity Cache between producer and
             # consumer, so some rates exceed what HBM alone gives; tiny finalize kernels are latency-, not bandwidth-bound)
             big = [r for r in hbm_rows if r["ms_per_cycle"] >= 0.2]
+            # a kernel that moves less than 1 MB per launch finishes in 3-8 us whatever its bytes: it is launch-latency bound and
+            # its "bandwidth" says nothing; the worst three are taken among the launches that can be bandwidth bound at all
+            streaming = [r for r in big if r["algorithmic_MB_per_launch"] >= 1.0]
             out["hbm"] = {"peak_GBps": HBM_PEAK_GBPS, "unit": "GB/s",
                           "bytes": "algorithmic: 4 B x (elements read once + written once) per launch, counted at the launch site",
-                          "worst_three": sorted(big, key=lambda r: r["frac_of_peak"])[:3],
+                          "worst_three": sorted(streaming, key=lambda r: r["frac_of_peak"])[:3],
+                          "latency_bound_under_1MB_per_launch": [r["kernel"] for r in big if r["algorithmic_MB_per_launch"] < 1.0],
                           "kernels_over_0.2ms_per_cycle": big,
                           "other_kernels_ms_per_cycle": sum(r["ms_per_cycle"] for r in hbm_rows),
                           "table": "profiles/r03_hbm_kernels.json (rocprofv3 durations of the same single-stream pass)"}
