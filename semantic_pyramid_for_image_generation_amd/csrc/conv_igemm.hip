@@ -1288,7 +1288,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (i >= total4) return;
     const float4* s = reinterpret_cast<const float4*>(slabs) + i;
     float4 a = s[0];
-    for (int k = 1; k < splits; ++k) {
+    int k = 1;
+    for (; k + 3 < splits; k += 4) {                        // four loads in flight, added in slab order (same bits as a plain loop)
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(reinterpret_cast<const float4*>(slabs + (size_t)(k + u) * slab_stride) + i);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; k < splits; ++k) {
         const float4 v = *(reinterpret_cast<const float4*>(slabs + (size_t)k * slab_stride) + i);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
