@@ -226,11 +226,14 @@ def main():
 
     layers = []
 
-    def cycle(lp_=None):
+    def cycle(lp_=None, lookahead=True):
+        # the loop is told the next batch, so that it can launch the next iteration's stage A ahead of this one's stage B
+        # (loop.TrainLoop.iteration); lookahead=False on the last cycle before the loop's mode is switched
         lp_ = lp_ or lp
-        for _ in range(5):
+        for j in range(5):
             it[0] += 1
-            lp_.iteration(pool[it[0] % len(pool)])
+            nxt = pool[(it[0] + 1) % len(pool)] if (lookahead or j < 4) else None
+            lp_.iteration(pool[it[0] % len(pool)], next_images=nxt)
             layers.append(lp_.features_to_train)
 
     def barrier():
@@ -247,6 +250,7 @@ def main():
         cycle()
     timing = not a.no_kernel_timing
     if a.profile_pass:
+        cycle(lookahead=False)          # (no stage A of a captured iteration left in flight)
         ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = ops.PREFETCH = False
         lp.use_graphs = False
         cycle()
@@ -341,6 +345,8 @@ def main():
     elapsed_instr = None
     hbm_rows = []
     if timing:
+        cycle(lookahead=False)          # (untimed: no stage A of a captured iteration left in flight when the mode changes)
+        barrier()
         # single-stream for this pass: a kernel's event-to-event time is only its own duration when nothing else shares the GPU
         saved = (ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH)
         ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = ops.PREFETCH = False

@@ -136,7 +136,8 @@ class TrainLoop:
         self.crit_f = criterion_features or tm.L1Loss()
         self.crit_dn = criterion_diversity_n or tm.L1Loss()
         self.crit_dd = criterion_diversity_d or tm.L1Loss()
-        self.iterations = 0
+        self.iterations = 0             # iterations drawn (one ahead of `current` while a stage A is launched ahead)
+        self.current = 0                # number of the iteration that the last iteration() call ran
         dev, B = self.device, batch_size
         self.image_size = image_size
         s_ = image_size
@@ -148,6 +149,7 @@ class TrainLoop:
         self._pools = {}
         self._cap_stream = None
         self._parity = 0
+        self._pending = None            # (key, parity, graphs, event, attributes) of an iteration whose stage A is already launched
         self.seen = set()
         self.features_to_train = None
         self.train_type = None
@@ -170,7 +172,7 @@ class TrainLoop:
         """The host-side draws of one iteration, in the reference's order (train_model.py:301 train type, :327 layer, :201
         crop, all from Python's `random`).  Returns the variant key (generator step?, train type 1?, layer)."""
         self.iterations += 1
-        it = self.iterations
+        it = self.current = self.iterations
         self.train_type = random.choices([1, 2], [self.train1_prob, 1 - self.train1_prob])
         L = random.randint(1, 4) if self.fixed_layer is None else self.fixed_layer
         self.features_to_train = L
@@ -299,9 +301,9 @@ class TrainLoop:
         if do_g:
             self.g_opt.advance()
 
-    def _replay(self, cap, key, images, parity):
-        """Launch the two captured stages of one iteration: stage A on the prefetch stream (behind the generator's last update
-        and behind the stage B that last read this parity's buffers), stage B on the current stream behind stage A."""
+    def _issue_a(self, cap, key, images, parity):
+        """Launch the captured stage A of one iteration on the prefetch stream: behind the generator's last update and behind
+        the stage B that last read this parity's buffers.  Returns the event behind it."""
         dev = self.device
         slot = self.slots[parity]
         main = ops._current_stream_obj(dev)
@@ -317,6 +319,13 @@ class TrainLoop:
             a_done.record(pre)
         finally:
             torch.cuda.set_stream(main)
+        return a_done
+
+    def _issue_b(self, cap, key, parity, a_done):
+        """Launch the captured stage B on the current stream, behind its stage A."""
+        dev = self.device
+        slot = self.slots[parity]
+        main = ops._current_stream_obj(dev)
         main.wait_event(a_done)
         self._advance_optimizers(key[0])
         cap.replay_b(main.cuda_stream)
@@ -328,29 +337,63 @@ class TrainLoop:
             tm.mark_generator_updated(self.G, dev)
         return cap.out
 
-    def iteration(self, images, log=False):
-        """One loop iteration on `images` ((B,3,H,W) in [0,1]; on the device and complete, or in (pinned) host memory -- it is
-        then uploaded on the prefetch stream).  `log`: also keep the loss scalars for pop_logged().  Returns {'d': {...},
-        'g': {...} | None, 'features', 'masks', 'images_d'}; the tensors of a replayed body are overwritten by the replayed
-        iteration after the next."""
+    def _next_variant(self):
+        """The draws of the next iteration and the captured graphs of its variant (captured now if it has been seen before)."""
         key = self.draw()
-        out = None
+        self._parity ^= 1
+        parity = self._parity
+        cap = None
         if self.use_graphs:
-            self._parity ^= 1
-            parity = self._parity
             cap = self.graphs.get((key, parity))
             if cap is None and (key, parity) in self.seen:
                 self._capture(key, parity)
                 cap = self.graphs[(key, parity)]
-            if cap is not None:
-                out = self._replay(cap, key, images, parity)
             self.seen.add((key, parity))
+        return key, parity, cap
+
+    def iteration(self, images, log=False, next_images=None):
+        """One loop iteration on `images` ((B,3,H,W) in [0,1]; on the device and complete, or in (pinned) host memory -- it is
+        then uploaded on the prefetch stream).  `log`: also keep the loss scalars for pop_logged().  Returns {'d': {...},
+        'g': {...} | None, 'features', 'masks', 'images_d'}; the tensors of a replayed body are overwritten by the replayed
+        iteration after the next (whose stage A the NEXT call launches, when that call is given `next_images`).
+
+        `next_images`: the batch of the NEXT call.  Stage A of the next iteration (its draws, taps, masks, generator forwards)
+        is then launched on the prefetch stream BEFORE this iteration's stage B is launched on the main stream -- unless this
+        iteration ends with a generator step, whose update the next stage A must see.  The host needs ~20 us per launch and a
+        stage B has ~400 of them, about as long as the GPU needs to run it: issued in program order, stage A of iteration i+1
+        reaches the GPU when stage B of iteration i is nearly done and the two never overlap (measured: 0.0 ms of overlap
+        between the prefetch stream and the others in a kernel trace); issued first, it runs beside that stage B.  The draws
+        (Python `random`, CPU and device generators) happen in the same order either way, and the results are identical.
+        The next call must pass that batch as `images`.  Callers that touch the generator between two calls (sampling,
+        checkpoints) pass None for that call."""
+        out = None
+        if self._pending is not None:
+            key, parity, cap, a_done, attrs = self._pending
+            self._pending = None
+            self._set_attrs(attrs)
+        else:
+            key, parity, cap = self._next_variant()
+            a_done = self._issue_a(cap, key, images, parity) if cap is not None else None
+        if cap is not None:
+            if next_images is not None and not key[0]:
+                attrs = self._get_attrs()
+                nkey, nparity, ncap = self._next_variant()
+                n_done = self._issue_a(ncap, nkey, next_images, nparity) if ncap is not None else None
+                self._pending = (nkey, nparity, ncap, n_done, self._get_attrs())
+                self._set_attrs(attrs)
+            out = self._issue_b(cap, key, parity, a_done)
         if out is None:
             out = self._body(key, None, images)
         self.last = out
         if log:
             self._log(out)
         return out
+
+    def _get_attrs(self):
+        return (self.train_type, self.features_to_train, self.specs, self.current)
+
+    def _set_attrs(self, attrs):
+        self.train_type, self.features_to_train, self.specs, self.current = attrs
 
     def _log(self, out):
         d, g = out['d'], out['g']
@@ -363,7 +406,7 @@ class TrainLoop:
             raise RuntimeError("TrainLoop: loss log is full; call pop_logged() at least every %d iterations" % self.LOG_ROWS)
         row = len(self._logged)
         ops.gather_scalars([v.detach() for v in vals], self.loss_log[row])
-        self._logged.append((row, self.iterations, g is not None, g is not None and 'diversity loss' in g))
+        self._logged.append((row, self.current, g is not None, g is not None and 'diversity loss' in g))
 
     def pop_logged(self):
         """[(iteration, {tag: float})] for the iterations logged since the last call (one device-to-host copy)."""

@@ -688,24 +688,32 @@ def _main():
     z2 = torch.randn(args.batch_size, 128, 1, 1).to(device)
     fixed_features = fixed_masks = fixed_features_diversity = None
     first_iter = True
+
+    def to_loop_input(data):
+        images, _ = data
+        if isinstance(images, (list, tuple)):
+            # raw decoded pixels: Resize / CenterCrop / ToTensor on the GPU (sempyr_resize_crop_normalize), on the loop's
+            # prefetch stream, where the iteration's first consumers run
+            with torch.cuda.stream(ops.prefetch_stream(device)):
+                images = imageio.batch_images(images, device)
+        return images
+
     print("Starting Training Loop...")
     for epoch in range(args.epochs):
         if hasattr(train_loader, 'sampler') and hasattr(train_loader.sampler, 'set_epoch'):
             train_loader.sampler.set_epoch(epoch)          # data-parallel runs: a new permutation every epoch, as the reference's shuffle
-        for data in train_loader:
+        for data, data_next in _with_next(train_loader, to_loop_input):
             iterations += 1
             if iterations % 30 == 1:
                 print('epoch:', epoch, ', iter', iterations, 'start, time =', time.time() - starting_time, 'seconds')
                 starting_time = time.time()
-            images, _ = data
-            if isinstance(images, (list, tuple)):
-                # raw decoded pixels: Resize / CenterCrop / ToTensor on the GPU (sempyr_resize_crop_normalize), on the loop's
-                # prefetch stream, where the iteration's first consumers run
-                with torch.cuda.stream(ops.prefetch_stream(device)):
-                    images = imageio.batch_images(images, device)
             # (a pinned host batch goes to the loop as it is: the upload is issued on the loop's prefetch stream, in front of
-            # the work that reads it, instead of on this stream behind the previous iteration's backward pass)
-            out = loop.iteration(images, log=writer is not None)
+            # the work that reads it, instead of on this stream behind the previous iteration's backward pass.  The loop is
+            # also given the NEXT batch: it launches that iteration's stage A ahead of this one's stage B -- never across a
+            # generator step, so the sampling / checkpoint blocks below (iterations % 1000 == 1, generator-step iterations)
+            # see no work in flight that reads or writes the two networks)
+            images = data
+            out = loop.iteration(images, log=writer is not None, next_images=data_next)
             if first_iter and rank == 0:
                 first_iter = False
                 torch.cuda.current_stream(device).wait_stream(ops.prefetch_stream(device))     # (device-transformed images are produced there)
@@ -755,6 +763,20 @@ def _main():
                 if iterations % 20000 == 1:
                     torch.save(generator.state_dict(), models_dir + '/' + args.model_name + 'G_' + str(iterations // 15000))
                     torch.save(discriminator.state_dict(), models_dir + '/' + args.model_name + 'D_' + str(iterations // 15000))
+
+
+def _with_next(iterable, prepare):
+    """(prepare(item), prepare(next item) | None) over `iterable`, each item prepared once, one item ahead"""
+    it = iter(iterable)
+    try:
+        cur = prepare(next(it))
+    except StopIteration:
+        return
+    for nxt in it:
+        nxt = prepare(nxt)
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
 
 
 def build_parser():

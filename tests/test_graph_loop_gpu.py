@@ -37,14 +37,14 @@ def _make(dev, use_graphs, executor='own', B=4, norm='instance_norm', gen_type='
     return G, D, loop.TrainLoop(G, D, C, g_opt, d_opt, B, dev, use_graphs=use_graphs, executor=executor)
 
 
-def _run(dev, use_graphs, executor, iters, prepare, **kw):
+def _run(dev, use_graphs, executor, iters, prepare, lookahead=False, **kw):
     G, D, lp = _make(dev, use_graphs, executor, **kw)
     pool = [recipes.image_batch(40 + i, lp.B).to(dev) for i in range(3)]
     if prepare:
         lp.prepare()
     torch.manual_seed(7); random.seed(7)
     for i in range(iters):
-        lp.iteration(pool[i % 3], log=True)
+        lp.iteration(pool[i % 3], log=True, next_images=pool[(i + 1) % 3] if lookahead and i + 1 < iters else None)
     logged = lp.pop_logged()
     torch.cuda.synchronize()
     state = {('G', k): v.detach().clone() for k, v in G.state_dict().items()}
@@ -66,6 +66,19 @@ def test_replay_bit_identical_to_eager(dev, executor):
     assert sum(1 for _, d in le if 'G/g_loss' in d) == 2        # iterations 1 and 6 end with a generator step
     for k in se:
         assert torch.equal(se[k], sg[k]), k
+
+
+def test_lookahead_launch_order_changes_nothing(dev):
+    """iteration(next_images=...): stage A of iteration i+1 is launched ahead of stage B of iteration i (when that one has no
+    generator step); 12 iterations with three generator steps, prepared and captured-on-the-fly: same bits as all-eager"""
+    le, se, _ = _run(dev, False, 'own', 12, False)
+    for prepare in (True, False):
+        lg, sg, lp = _run(dev, True, 'own', 12, prepare, lookahead=True)
+        assert lp._pending is None
+        assert [d for _, d in le] == [d for _, d in lg]
+        assert [it for it, _ in lg] == list(range(1, 13))
+        for k in se:
+            assert torch.equal(se[k], sg[k]), (prepare, k)
 
 
 def test_replay_without_prepare_captures_on_second_occurrence(dev):
