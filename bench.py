@@ -232,8 +232,9 @@ def main():
         lp_ = lp_ or lp
         for j in range(5):
             it[0] += 1
-            nxt = pool[(it[0] + 1) % len(pool)] if (lookahead or j < 4) else None
-            lp_.iteration(pool[it[0] % len(pool)], next_images=nxt)
+            ahead = lp_.lookahead if lookahead else min(lp_.lookahead, 4 - j)
+            nxt = [pool[(it[0] + 1 + a) % len(pool)] for a in range(ahead)]
+            lp_.iteration(pool[it[0] % len(pool)], next_images=nxt or None)
             layers.append(lp_.features_to_train)
 
     def barrier():

@@ -11,11 +11,12 @@ with different dependencies:
     generator's last update;
   * stage B (critic step [+ generator step]) depends on stage A and on the previous stage B.
 
-Replayed, stage A of iteration i+1 is launched on the prefetch stream right after stage B of iteration i has been queued on
-the main stream, so it runs UNDER that step's backward pass -- the same overlap the eager three-stream schedule has, without
-the host in the way (one captured graph per iteration cannot do this: round 2 measured it slower than eager).  Two stage-A
-graphs in flight need two sets of static inputs / outputs: every variant is captured twice ("parity" = iteration & 1), and
-stage A of iteration i+2 waits for the event behind stage B of iteration i, whose buffers it overwrites.
+Replayed, stage A of the next `lookahead` iterations is launched on the prefetch stream BEFORE stage B of iteration i is
+launched on the main stream (iteration(next_images=...)), so it runs under that step's backward pass and in the gaps at
+the iteration boundaries (Adam, weight re-pack, the small kernels at the head of a stage) -- one captured graph per
+iteration cannot do this: round 2 measured it slower than eager.  k stage-A graphs in flight need k+1 sets of static
+inputs / outputs: every variant is captured once per buffer set ("parity" = iteration number modulo lookahead + 1), and
+stage A of iteration i waits for the event behind stage B of iteration i - (lookahead + 1), whose buffers it overwrites.
 
   * the variants are keyed by what changes the kernel sequence: whether the iteration ends with a generator step, the
     train type and the selected layer L (the number of feature-loss terms; which masks are all-zero);
@@ -45,6 +46,11 @@ _USE_GRAPHS_ENV = os.environ.get("SEMPYR_GRAPHS", "1") != "0"
 # streams); "hip" = hipGraphLaunch through torch (kept for A/B: in ROCm 7.2 it runs the branches one after the other)
 _GRAPH_EXEC_ENV = os.environ.get("SEMPYR_GRAPH_EXEC", "own")
 _REPLAY_STREAMS = int(os.environ.get("SEMPYR_REPLAY_STREAMS", "3"))
+# how many iterations ahead of the running stage B a stage A may be launched (= sets of static buffers - 1).  Measured
+# on the headline configuration (tools/la_sweep.sh): 1 -> 45.3, 2 -> 44.9, 3 -> 44.9 ms per cycle, i.e. nothing beyond the
+# run-to-run spread: with one stage A beside every stage B the GPU has no idle share left to fill, so the default stays at
+# the smallest memory footprint (two buffer sets, 16 captured graphs).
+_LOOKAHEAD_ENV = max(1, int(os.environ.get("SEMPYR_LOOKAHEAD", "1")))
 
 
 class _Slot:
@@ -117,6 +123,7 @@ class TrainLoop:
 
     def __init__(self, generator, discriminator, classifier, generator_optimizer, discriminator_optimizer, batch_size, device,
                  discriminator_steps=5, train1_prob=0.6, fixed_layer=None, use_graphs=None, executor=None, image_size=256,
+                 lookahead=None,
                  normalizer_clf=None, normalizer_discriminator=None, criterion_features=None, criterion_diversity_n=None,
                  criterion_diversity_d=None):
         self.G, self.D, self.C = generator, discriminator, classifier
@@ -148,8 +155,10 @@ class TrainLoop:
         self.graphs = {}                # (variant key, parity) -> _Captured
         self._pools = {}
         self._cap_stream = None
-        self._parity = 0
-        self._pending = None            # (key, parity, graphs, event, attributes) of an iteration whose stage A is already launched
+        self.lookahead = _LOOKAHEAD_ENV if lookahead is None else max(1, int(lookahead))
+        self.nslots = self.lookahead + 1
+        self._parity = 0                # the buffer set ("parity": iteration number modulo nslots) of the iteration drawn last
+        self._ahead = []                # [(key, parity, graphs, event, attributes)] of iterations whose stage A is already launched
         self.seen = set()
         self.features_to_train = None
         self.train_type = None
@@ -165,7 +174,7 @@ class TrainLoop:
 
     def _slots(self):
         if self.slots is None:
-            self.slots = [_Slot(self.B, self.image_size, self.tap_shapes, self.device) for _ in range(2)]
+            self.slots = [_Slot(self.B, self.image_size, self.tap_shapes, self.device) for _ in range(self.nslots)]
         return self.slots
 
     def draw(self):
@@ -340,7 +349,7 @@ class TrainLoop:
     def _next_variant(self):
         """The draws of the next iteration and the captured graphs of its variant (captured now if it has been seen before)."""
         key = self.draw()
-        self._parity ^= 1
+        self._parity = (self._parity + 1) % self.nslots
         parity = self._parity
         cap = None
         if self.use_graphs:
@@ -357,29 +366,35 @@ class TrainLoop:
         'g': {...} | None, 'features', 'masks', 'images_d'}; the tensors of a replayed body are overwritten by the replayed
         iteration after the next (whose stage A the NEXT call launches, when that call is given `next_images`).
 
-        `next_images`: the batch of the NEXT call.  Stage A of the next iteration (its draws, taps, masks, generator forwards)
-        is then launched on the prefetch stream BEFORE this iteration's stage B is launched on the main stream -- unless this
-        iteration ends with a generator step, whose update the next stage A must see.  The host needs ~20 us per launch and a
+        `next_images`: the batch of the NEXT call, or a list with the batches of the next calls in order (`lookahead` of them
+        are used).  Stage A of those iterations (draws, taps, masks, generator forwards) is then launched on the prefetch
+        stream BEFORE this iteration's stage B is launched on the main stream -- up to and including the first iteration that
+        ends with a generator step, whose update every later stage A must see.  The host needs ~20 us per launch and a
         stage B has ~400 of them, about as long as the GPU needs to run it: issued in program order, stage A of iteration i+1
         reaches the GPU when stage B of iteration i is nearly done and the two never overlap (measured: 0.0 ms of overlap
         between the prefetch stream and the others in a kernel trace); issued first, it runs beside that stage B.  The draws
         (Python `random`, CPU and device generators) happen in the same order either way, and the results are identical.
-        The next call must pass that batch as `images`.  Callers that touch the generator between two calls (sampling,
+        The next calls must pass those batches as `images`, in that order.  Callers that touch the generator between two calls (sampling,
         checkpoints) pass None for that call."""
         out = None
-        if self._pending is not None:
-            key, parity, cap, a_done, attrs = self._pending
-            self._pending = None
+        if self._ahead:
+            key, parity, cap, a_done, attrs = self._ahead.pop(0)
             self._set_attrs(attrs)
         else:
             key, parity, cap = self._next_variant()
             a_done = self._issue_a(cap, key, images, parity) if cap is not None else None
         if cap is not None:
-            if next_images is not None and not key[0]:
+            if next_images is not None:
+                upcoming = list(next_images) if isinstance(next_images, (list, tuple)) else [next_images]
                 attrs = self._get_attrs()
-                nkey, nparity, ncap = self._next_variant()
-                n_done = self._issue_a(ncap, nkey, next_images, nparity) if ncap is not None else None
-                self._pending = (nkey, nparity, ncap, n_done, self._get_attrs())
+                # a stage A must see every generator update in front of it; an eagerly issued iteration draws its device
+                # inputs when it is called, so nothing behind it may draw earlier
+                blocked = key[0] or any(e[0][0] or e[2] is None for e in self._ahead)
+                while not blocked and len(self._ahead) < min(len(upcoming), self.lookahead):
+                    nkey, nparity, ncap = self._next_variant()
+                    n_done = self._issue_a(ncap, nkey, upcoming[len(self._ahead)], nparity) if ncap is not None else None
+                    self._ahead.append((nkey, nparity, ncap, n_done, self._get_attrs()))
+                    blocked = nkey[0] or ncap is None
                 self._set_attrs(attrs)
             out = self._issue_b(cap, key, parity, a_done)
         if out is None:
@@ -454,13 +469,13 @@ class TrainLoop:
         warmed = set()
         for key in keys:
             do_g, is1, L = key
-            for parity in (0, 1):
+            for parity in range(self.nslots):
                 if (key, parity) in self.graphs:
                     continue
                 self.specs = tm.mask_specs(shapes, is1, L, None if is1 else (30, 30))
                 ops.store_words(slots[parity].spec_dev, tm.spec_words(self.specs))
                 torch.cuda.synchronize(self.device)      # (the eager body starts on the prefetch stream, which does not follow this one)
-                if key not in warmed and not any((key, q) in self.seen for q in (0, 1)):
+                if key not in warmed and not any((key, q) in self.seen for q in range(self.nslots)):
                     self._body(key, self._slot_inputs(slots[parity]))
                     torch.cuda.synchronize(self.device)
                 warmed.add(key)

@@ -702,7 +702,7 @@ def _main():
     for epoch in range(args.epochs):
         if hasattr(train_loader, 'sampler') and hasattr(train_loader.sampler, 'set_epoch'):
             train_loader.sampler.set_epoch(epoch)          # data-parallel runs: a new permutation every epoch, as the reference's shuffle
-        for data, data_next in _with_next(train_loader, to_loop_input):
+        for data, data_next in _with_next(train_loader, to_loop_input, loop.lookahead):
             iterations += 1
             if iterations % 30 == 1:
                 print('epoch:', epoch, ', iter', iterations, 'start, time =', time.time() - starting_time, 'seconds')
@@ -765,18 +765,18 @@ def _main():
                     torch.save(discriminator.state_dict(), models_dir + '/' + args.model_name + 'D_' + str(iterations // 15000))
 
 
-def _with_next(iterable, prepare):
-    """(prepare(item), prepare(next item) | None) over `iterable`, each item prepared once, one item ahead"""
+def _with_next(iterable, prepare, n=1):
+    """(prepare(item), [prepare() of the up to n items that follow]) over `iterable`; every item is prepared once"""
     it = iter(iterable)
-    try:
-        cur = prepare(next(it))
-    except StopIteration:
-        return
-    for nxt in it:
-        nxt = prepare(nxt)
-        yield cur, nxt
-        cur = nxt
-    yield cur, None
+    window = []
+    for item in it:
+        window.append(prepare(item))
+        if len(window) == n + 1:
+            yield window[0], window[1:]
+            window.pop(0)
+    while window:
+        yield window[0], (window[1:] or None)
+        window.pop(0)
 
 
 def build_parser():

@@ -18,7 +18,7 @@ from oracle import recipes
 pytestmark = pytest.mark.gpu
 
 
-def _make(dev, use_graphs, executor='own', B=4, norm='instance_norm', gen_type='res', div=False, seed=11):
+def _make(dev, use_graphs, executor='own', B=4, norm='instance_norm', gen_type='res', div=False, seed=11, depth=None):
     from semantic_pyramid_for_image_generation_amd import loop, optim
     from semantic_pyramid_for_image_generation_amd import train_model as tm
     from semantic_pyramid_for_image_generation_amd.classifier import Classifier, resnet18
@@ -34,7 +34,7 @@ def _make(dev, use_graphs, executor='own', B=4, norm='instance_norm', gen_type='
     tm.args = Namespace(use_diversity_loss=div, gradient_penalty_weight=10.0)
     g_opt = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
     d_opt = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
-    return G, D, loop.TrainLoop(G, D, C, g_opt, d_opt, B, dev, use_graphs=use_graphs, executor=executor)
+    return G, D, loop.TrainLoop(G, D, C, g_opt, d_opt, B, dev, use_graphs=use_graphs, executor=executor, lookahead=depth)
 
 
 def _run(dev, use_graphs, executor, iters, prepare, lookahead=False, **kw):
@@ -44,7 +44,8 @@ def _run(dev, use_graphs, executor, iters, prepare, lookahead=False, **kw):
         lp.prepare()
     torch.manual_seed(7); random.seed(7)
     for i in range(iters):
-        lp.iteration(pool[i % 3], log=True, next_images=pool[(i + 1) % 3] if lookahead and i + 1 < iters else None)
+        nxt = [pool[j % 3] for j in range(i + 1, min(i + 1 + lp.lookahead, iters))] if lookahead else None
+        lp.iteration(pool[i % 3], log=True, next_images=nxt or None)
     logged = lp.pop_logged()
     torch.cuda.synchronize()
     state = {('G', k): v.detach().clone() for k, v in G.state_dict().items()}
@@ -56,7 +57,7 @@ def _run(dev, use_graphs, executor, iters, prepare, lookahead=False, **kw):
 def test_replay_bit_identical_to_eager(dev, executor):
     le, se, _ = _run(dev, False, 'own', 7, False)
     lg, sg, lp = _run(dev, True, executor, 7, True)
-    assert len(lp.graphs) == 16                                 # (generator step or not) x layer 1..4 x pipeline parity, all captured by prepare()
+    assert len(lp.graphs) == 8 * lp.nslots                      # (generator step or not) x layer 1..4 x buffer set, all captured by prepare()
     if executor == 'own':
         stats = lp.graphs[((False, False, 1), 0)].stats
         assert stats[0] > 200 and stats[2] == 0 and stats[4] >= 2      # kernels; no memcpy nodes; more than one stream
@@ -69,12 +70,13 @@ def test_replay_bit_identical_to_eager(dev, executor):
 
 
 def test_lookahead_launch_order_changes_nothing(dev):
-    """iteration(next_images=...): stage A of iteration i+1 is launched ahead of stage B of iteration i (when that one has no
-    generator step); 12 iterations with three generator steps, prepared and captured-on-the-fly: same bits as all-eager"""
+    """iteration(next_images=[...]): stage A of the next 1..3 iterations is launched ahead of stage B of iteration i (never
+    across a generator step); 12 iterations with three generator steps, prepared and captured-on-the-fly: same bits as
+    all-eager"""
     le, se, _ = _run(dev, False, 'own', 12, False)
-    for prepare in (True, False):
-        lg, sg, lp = _run(dev, True, 'own', 12, prepare, lookahead=True)
-        assert lp._pending is None
+    for prepare, depth in ((True, 1), (True, 2), (False, 2), (True, 3)):
+        lg, sg, lp = _run(dev, True, 'own', 12, prepare, lookahead=True, depth=depth)
+        assert lp._ahead == [] and lp.nslots == depth + 1
         assert [d for _, d in le] == [d for _, d in lg]
         assert [it for it, _ in lg] == list(range(1, 13))
         for k in se:
@@ -85,7 +87,7 @@ def test_replay_without_prepare_captures_on_second_occurrence(dev):
     """a variant runs eagerly when first met and is captured when met again: same results as all-eager"""
     le, se, _ = _run(dev, False, 'own', 14, False, B=2, norm='layer_norm')
     lg, sg, lp = _run(dev, True, 'own', 14, False, B=2, norm='layer_norm')
-    assert 1 <= len(lp.graphs) <= 7          # (variant, parity) pairs met at least twice in 14 iterations
+    assert 1 <= len(lp.graphs) <= 7          # (variant, buffer set) pairs met at least twice in 14 iterations
     assert [d for _, d in le] == [d for _, d in lg]
     for k in se:
         assert torch.equal(se[k], sg[k]), k
