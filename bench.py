@@ -453,7 +453,7 @@ def main():
                 traffic_note = f"{top['name']}: measured {traffic / 1e6:.0f} MB vs algorithmic {top['algorithmic_bytes'] / 1e6:.0f} MB per launch"
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_of": traffic_note,
-                               "kernel": "implicit-GEMM conv kernels on fp32 v_mfma_f32_32x32x2_f32 (igemm_kernel fwd/dgrad/wgrad, patch3x3_kernel, tpatch_kernel; incl. the VALU RGB-head launches)",
+                               "kernel": "implicit-GEMM conv kernels on fp32 v_mfma_f32_32x32x2_f32 (igemm_kernel fwd/dgrad/wgrad, patch3x3_kernel, tpatch_kernel, wpatch_kernel; incl. the VALU RGB-head launches)",
                                "launches": int(kl.value), "avg_launch_us": 1000.0 * kms.value / kl.value,
                                "kernel_ms_total": kms.value, "kernel_time_share": kms.value * 1e-3 / elapsed_instr,
                                "instrumented_ms_per_step": 1000.0 * elapsed_instr / a.steps,

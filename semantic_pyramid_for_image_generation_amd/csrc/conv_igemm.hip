@@ -1602,7 +1602,8 @@ __global__ __launch_bounds__(256) void pack_weights_many_kernel(const PackManyAr
 // host side
 // ------------------------------------------------------------------------------------------
 enum { CFG_128x128 = 0, CFG_64x256 = 1, CFG_32x256 = 2, CFG_64x64 = 3, CFG_64x192 = 4, CFG_64x128 = 5,
-       CFG_TPATCH = 6 /* 4x4 / stride-2 patch kernels: the tile comes from tp_pick() */ };
+       CFG_TPATCH = 6 /* 4x4 / stride-2 patch kernels: the tile comes from tp_pick() */,
+       CFG_WPATCH = 7 /* row-ring weight-gradient kernel: the slabs come from wp_pick() */ };
 
 // Tile shape for a GATHER launch over N pixels (all stride phases of a DGRAD together).  `kind`: the kernel the launch
 // will run on — the choices below are measured (tools/bench_conv.py mid / small with SEMPYR_FORCE_CFG*).
@@ -1968,6 +1969,7 @@ int try_patch(const sempyr_conv_desc* d, int mode, int cfg, IgemmParams& p, int 
 }
 
 #include "conv_tpatch_host.h"
+#include "conv_wpatch.h"
 
 template <int MODE>
 int launch_cfg(int cfg, const IgemmParams& p, int splits, bool uniform_tap, hipStream_t st) {
@@ -2074,6 +2076,8 @@ extern "C" int sempyr_conv2d_plan(const sempyr_conv_desc* d, int mode, sempyr_co
         plan->wpack_floats = 0;
         int cps;
         pick_splits(ceil_div(plan->Mpad, bm) * ceil_div(Nn, bn), plan->Kpad[0] / BK, plan->splits[0], cps, target_blocks_wgrad());
+        WpPick wp;
+        if (!rgb_wgrad_ok(d) && wp_pick(d, g.Ho, g.Wo, wp)) { plan->cfg = CFG_WPATCH; plan->splits[0] = wp.nslabs; }
         plan->workspace_bytes = (long long)plan->splits[0] * d->Cout * Nn * 4;
         if (rgb_wgrad_ok(d)) {
             const long long need = (long long)d->B * ceil_div(d->Hin, rgbw_rows()) * d->Cin * d->Cout * 9 * 4;
@@ -2446,6 +2450,13 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
         SEMPYR_CHECK_LAUNCH();
         return 0;
     }
+    const int splits = pl.splits[0];
+    const long long slab_stride = (long long)d->Cout * Nn;
+    if (pl.cfg == CFG_WPATCH) {
+        WpPick wp;
+        if (!wp_pick(d, pl.Ho, pl.Wo, wp) || wp.nslabs != splits) SEMPYR_FAIL("conv wgrad: plan and launch disagree");
+        if (int rc = wp_launch(d, wp, pl.Ho, pl.Wo, gy, x, (float*)ws, st)) return rc;
+    } else {
     IgemmParams p{};
     p.A = gy; p.X = x; p.ktab = reinterpret_cast<const int2*>(ktab);
     p.M = d->Cout; p.Mpad = pl.Mpad; p.N = Nn; p.K = pl.K[0]; p.Kpad = pl.Kpad[0];
@@ -2455,23 +2466,23 @@ extern "C" int sempyr_conv2d_wgrad(const sempyr_conv_desc* d, const float* gy, c
     p.QH = pl.Ho; p.QW = pl.Wo; p.QHW = pl.Ho * pl.Wo; p.dQHW.init(p.QHW); p.dQW.init(p.QW);
     p.ldc = Nn;
     p.nchunks = pl.Kpad[0] / BK;
-    const int splits = pl.splits[0];
     p.chunks_per_split = ceil_div(p.nchunks, splits);
-    p.Out = (float*)ws; p.slab_stride = (long long)d->Cout * Nn;
+    p.Out = (float*)ws; p.slab_stride = slab_stride;
     p.x_bytes = d->B * p.XCHW * 4; p.a_bytes = d->B * d->Cout * pl.Ho * pl.Wo * 4;
     if (int rc = launch_cfg<MODE_WGRAD>(pl.cfg, p, splits, d->Cin % BK == 0, st)) return rc;
+    }
     const int total = d->Cout * d->Cin * T;
     static const int reduce_t = env_int("SEMPYR_WGRAD_REDUCE_T", 1);
     HbmScope hs("wgrad_reduce_kernel (all forms)", 4.0 * (double)total * (splits + 1.0 + (accumulate ? 1.0 : 0.0)), st);
     if (splits >= 64)
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(ceil_div(total, 16)), dim3(256), 0, st,
-                           (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
+                           (const float*)ws, gw, splits, slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
     else if (reduce_t && T > 1 && d->Cin >= 32 && d->Cout * ceil_div(d->Cin, 64) >= 512)     // fewer workgroups: one thread per output wins (measured)
         hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(d->Cout * ceil_div(d->Cin, 64)), dim3(256), (size_t)64 * (T + 1) * sizeof(float), st,
-                           (const float*)ws, gw, splits, p.slab_stride, d->Cin, T, Nn, accumulate ? 1 : 0);
+                           (const float*)ws, gw, splits, slab_stride, d->Cin, T, Nn, accumulate ? 1 : 0);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st,
-                           (const float*)ws, gw, splits, p.slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
+                           (const float*)ws, gw, splits, slab_stride, d->Cout, d->Cin, T, Nn, accumulate ? 1 : 0);
     SEMPYR_CHECK_LAUNCH();
     return 0;
 }

@@ -148,6 +148,36 @@ def test_conv4x4s2_patch_kernels(dev, case):
         assert rel_err(bd.grad, br.grad) < tol
 
 
+WPATCH_CASES = [
+    (3, 128, 7, 128, 64, 0),      # two 64-channel column blocks, 2 column strips, 7 rows in chunks of 4 + 3
+    (2, 64, 16, 64, 128, 0),      # two 64-row blocks
+    (2, 64, 6, 64, 64, 1),        # behind the fused nearest upsample: 12 output rows x 128 columns from 6 x 64 stored
+    (2, 128, 8, 32, 64, 1),       # upsampled to 16 x 64: one strip, two 64-channel column blocks
+]
+
+
+@pytest.mark.parametrize("case", WPATCH_CASES)
+def test_conv3x3_row_ring_weight_gradient(dev, case):
+    """the LDS row-ring WGRAD kernel (csrc/conv_wpatch.h) against torch fp64, through the module-level op"""
+    ops = _ops()
+    from semantic_pyramid_for_image_generation_amd._lib import CONV_WGRAD
+    B, Cin, H, W, Cout, ups = case
+    plan = ops.get_plan((B, Cin, H, W, Cout, 3, 3, 1, 1, ups), dev)
+    assert plan.mode(CONV_WGRAD).info.cfg == 7, "not on the row-ring kernel"
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    gy = torch.randn(B, Cout, H << ups, W << ups, generator=g)
+    xr = F.interpolate(x.double(), scale_factor=2, mode='nearest') if ups else x.double()
+    gwr = torch.nn.grad.conv2d_weight(xr, (Cout, Cin, 3, 3), gy.double(), stride=1, padding=1)
+    gw = ops._raw_conv_wgrad(plan, gy.to(dev), x.to(dev))
+    assert rel_err(gw, gwr) < 2e-5
+    gw2 = ops._raw_conv_wgrad(plan, gy.to(dev), x.to(dev))
+    assert torch.equal(gw, gw2)                     # fixed summation order: bit-identical from launch to launch
+    acc = gw.clone()
+    ops._raw_conv_wgrad(plan, gy.to(dev), x.to(dev), into=acc)          # `into`: the combine pass adds to what is there
+    assert rel_err(acc, 2 * gwr) < 2e-5
+
+
 def test_conv_transpose4x4s2_patch_kernel(dev):
     """ConvTranspose2d(4, 2, 1) forward = the per-phase input-gradient kernel (128 output channels: two row tiles); its
     backward = the forward patch kernel."""

@@ -4,7 +4,7 @@ conv families next to their algorithmic bytes.  rocprofv3 reports FETCH_SIZE / W
 the read figure is an estimate.  Infinity-Cache hits are counted as traffic."""
 import csv, glob, json, os
 O = 'gpurun_out/pmc_top3'
-CONV = ('igemm_kernel', 'patch3x3_kernel', 'tpatch_kernel')
+CONV = ('igemm_kernel', 'patch3x3_kernel', 'tpatch_kernel', 'wpatch_kernel')
 fams = []
 for line in open(os.path.join(O, 'families.txt')):
     i, name, mode, B, Cin, H, W, Cout, k, s, p, ups = line.split()

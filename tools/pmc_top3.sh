@@ -14,6 +14,7 @@ done <<'LIST'
 G.b7.conv2_64to64_3x3_at256_fwd fwd 16 64 256 256 64 3 1 1 0
 G.b7.conv1_64to64_3x3_ups128to256_fwd fwd 16 64 128 128 64 3 1 1 1
 G.b7.conv2_wgrad_64x576xK1M wgrad 16 64 256 256 64 3 1 1 0
+G.b7.conv1_wgrad_ups_64x576xK1M wgrad 16 64 128 128 64 3 1 1 1
 D.b1_64to64_4x4s2_at128_fwd fwd 16 64 128 128 64 4 2 1 0
 D.b3_128to256_4x4s2_at32_dgrad dgrad 16 128 32 32 256 4 2 1 0
 LIST
