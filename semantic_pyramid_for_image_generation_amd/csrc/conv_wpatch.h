@@ -274,7 +274,7 @@ inline bool wp_pick(const sempyr_conv_desc* d, int Ho, int Wo, WpPick& w) {
     // combine pass that the generic kernel's 96 slabs do not.
     static const int enabled = env_int("SEMPYR_WPATCH", 3);
     static const int target = env_int("SEMPYR_WPATCH_BLOCKS", 256);
-    static const int max_tiles = env_int("SEMPYR_WPATCH_MAX_TILES", 2);
+    static const int max_tiles = env_int("SEMPYR_WPATCH_MAX_TILES", 8);
     static const int min_rows = env_int("SEMPYR_WPATCH_MIN_ROWS", 4);
     // (whatever d->math says: weight gradients are always fp32 products, so that both arithmetic modes give the same bits)
     if (d->Cin % 64 != 0 || d->Cout % 64 != 0 || d->pad != 1 || d->kh != d->kw || d->Win % 4 != 0) return false;

@@ -14,6 +14,7 @@ SHAPES = [   # name, B, Cin, H, W (stored input), Cout, k, stride, ups
     ('G.b6.conv2 64->64 @128', 16, 64, 128, 128, 64, 3, 1, 0),
     ('G.b6.conv1 ups 128->64 @64', 16, 128, 64, 64, 64, 3, 1, 1),
     ('G.b5 128->128 @64', 16, 128, 64, 64, 128, 3, 1, 0),
+    ('G.b5.conv1 ups 256->128 @32', 16, 256, 32, 32, 128, 3, 1, 1),
     ('D.b1 64->64 @128', 16, 64, 128, 128, 64, 4, 2, 0),
     ('D.b1 64->64 @128 B32', 32, 64, 128, 128, 64, 4, 2, 0),
     ('D.b2 64->128 @64', 16, 64, 64, 64, 128, 4, 2, 0),
