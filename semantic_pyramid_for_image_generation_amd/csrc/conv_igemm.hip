@@ -1155,6 +1155,79 @@ __global__ __launch_bounds__(256) void gather_small_m_kernel(const IgemmParams p
         if (m < p.M) op[(size_t)m * p.OHW] = act_apply(a[m] + (p.bias ? p.bias[m] : 0.f), p.act, p.slope);
 }
 
+// The same shapes with the loops the other way round (channel outer, tap inner) -- the classifier stem's input gradient
+// (7x7 / stride 2, 64 -> 3 channels, resnet.py conv1; the generator step's feature loss reaches the image through it) and
+// ConvTranspose image heads.  gather_small_m_kernel walks the packed reduction order (tap outer, channel inner): between two
+// taps that touch the same rows of a channel plane lie the planes of all other channels, times every wave on the CU, so
+// each of its loads went to L2 (measured 544 us for 4.9 GFLOP = 0.06 of the matrix peak, 9 TFLOP/s on the vector ALU).
+// Here a lane keeps the NT tap offsets of its pixel in registers (out-of-image taps point beyond the buffer: zero fill),
+// so a channel costs NT loads from the SAME few rows (L1 hits), no address arithmetic, and NT broadcast LDS reads of the
+// phase's weights (staged once per workgroup as float4 [tap][channel]).
+template <int NT>
+__device__ __forceinline__ void small_m_cmajor_body(const IgemmParams& p, const float4* wl, const unsigned (&voff)[16], int C,
+                                                    float& acc0, float& acc1, float& acc2, float& acc3)
+{
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    for (int c = 0; c < C; ++c) {
+        const int so = c * p.XHW * 4;
+        float xv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (int)voff[t], so, 0));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 w = wl[t * C + c];
+            acc0 += xv[t] * w.x; acc1 += xv[t] * w.y; acc2 += xv[t] * w.z; acc3 += xv[t] * w.w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void small_m_cmajor_kernel(const IgemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 wl[];       // [16][C]; taps beyond the phase's: zeros
+    int id = blockIdx.x;
+    const float* pA = p.A; const int2* pktab = p.ktab;
+    int pN = p.N, pnchunks = p.nchunks, pQW = p.QW, pQHW = p.QHW, pOPY = p.OPY, pOPX = p.OPX;
+    if (p.nphases > 1) {
+        const int phase = id % p.nphases; id /= p.nphases;
+        pA += p.ph[phase].a_off; pktab += p.ph[phase].tab_off;
+        pN = p.ph[phase].N; pnchunks = p.ph[phase].nchunks; pQW = p.ph[phase].QW; pQHW = p.ph[phase].QHW;
+        pOPY = p.ph[phase].OPY; pOPX = p.ph[phase].OPX;
+    }
+    if (id * 256 >= pN) return;
+    const int C = p.C;
+    const int ntaps = pnchunks * BK / C;                       // (the host checked: C % BK == 0, ntaps <= 16)
+    for (int k = threadIdx.x; k < 16 * C; k += 256)
+        wl[k] = k < ntaps * C ? *reinterpret_cast<const float4*>(pA + (size_t)k * p.Mpad) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = id * 256 + threadIdx.x;
+    const bool valid = n < pN;
+    const int nn = valid ? n : 0;
+    const int b = nn / pQHW;
+    const int r = nn - b * pQHW;
+    const int qy = r / pQW;
+    const int qx = r - qy * pQW;
+    const int ybase = qy * p.SY, xbase = qx * p.SX;
+    unsigned voff[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int2 ent = pktab[(t < ntaps ? t : 0) * C];
+        const int iy = ybase + (ent.y >> 16), ix = xbase + (int)(short)(ent.y & 0xffff);
+        const bool ok = valid && t < ntaps && ((unsigned)iy < (unsigned)p.GH) & ((unsigned)ix < (unsigned)p.GW);
+        voff[t] = ok ? 4u * (unsigned)(b * p.XCHW + iy * p.XW + ix) : 0x80000000u;
+    }
+    __syncthreads();
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    if (ntaps <= 4) small_m_cmajor_body<4>(p, wl, voff, C, acc0, acc1, acc2, acc3);
+    else if (ntaps <= 9) small_m_cmajor_body<9>(p, wl, voff, C, acc0, acc1, acc2, acc3);
+    else if (ntaps <= 12) small_m_cmajor_body<12>(p, wl, voff, C, acc0, acc1, acc2, acc3);
+    else small_m_cmajor_body<16>(p, wl, voff, C, acc0, acc1, acc2, acc3);
+    if (!valid) return;
+    float* op = p.Out + (size_t)b * p.OCHW + (qy * p.OSY + pOPY) * p.OW + qx * p.OSX + pOPX;
+    const float a[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (m < p.M) op[(size_t)m * p.OHW] = act_apply(a[m] + (p.bias ? p.bias[m] : 0.f), p.act, p.slope);
+}
+
 // 3x3 / stride 1 / pad 1 convolution with at most 4 output rows on the vector ALU (generator image head
 // generator.py:116, and the input gradient of the critic's 3x3 stem discriminator.py:95): 4 consecutive pixels per
 // lane, so a channel costs 3 rows x (one float4 + the two edge pixels) = 9 loads for 108 FMAs; the 9 taps of a channel
@@ -1824,7 +1897,16 @@ int launch_small_m(const IgemmParams& p, bool uniform_tap, hipStream_t st) {
         }
     }
     if (e0) (void)hipEventRecord(e0, st);
-    if (uniform_tap) hipLaunchKernelGGL(gather_small_m_kernel<true>, grid, dim3(256), 0, st, pp);
+    // channel-major walk: whole taps of C channels each (uniform_tap and no K padding), at most 16 taps per phase, no fused
+    // upsample, packed rows of at least 4 floats, and the gathered tensor inside one buffer descriptor
+    static const int cmajor = env_int("SEMPYR_SMALL_M_CMAJOR", 1);
+    bool cm = cmajor && uniform_tap && p.ups == 0 && p.C > 0 && p.C <= 256 && p.C % BK == 0 && p.Mpad >= 4 && !p.GP;
+    if (cm) {
+        if (pp.nphases > 1) { for (int i = 0; i < pp.nphases; ++i) if (pp.ph[i].N > 0 && (pp.ph[i].nchunks * BK % p.C != 0 || pp.ph[i].nchunks * BK / p.C > 16)) cm = false; }
+        else if (p.nchunks * BK % p.C != 0 || p.nchunks * BK / p.C > 16) cm = false;
+    }
+    if (cm) hipLaunchKernelGGL(small_m_cmajor_kernel, grid, dim3(256), (size_t)16 * p.C * sizeof(float4), st, pp);
+    else if (uniform_tap) hipLaunchKernelGGL(gather_small_m_kernel<true>, grid, dim3(256), 0, st, pp);
     else hipLaunchKernelGGL(gather_small_m_kernel<false>, grid, dim3(256), 0, st, pp);
     if (e1) (void)hipEventRecord(e1, st);
     SEMPYR_CHECK_LAUNCH();
