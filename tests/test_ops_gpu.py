@@ -714,3 +714,38 @@ def test_no_cpu_fallback():
     from semantic_pyramid_for_image_generation_amd import ops, _lib
     with pytest.raises(_lib.SempyrError):
         ops.conv2d(torch.randn(1, 3, 8, 8), torch.randn(4, 3, 3, 3), None, 1, 1)
+
+
+def test_multi_tensor_repack_matches_single_packs(dev):
+    """sempyr_conv2d_pack_weights_many (every cached layout of a module in one launch, behind its optimizer step) fills the
+    cached buffers with exactly what the per-tensor pack kernel writes: tables with and without padding rows / columns"""
+    ops = _ops()
+    from semantic_pyramid_for_image_generation_amd._lib import CONV_FWD, CONV_DGRAD
+    g = torch.Generator().manual_seed(41)
+    shapes = [(2, 64, 16, 16, 128, 4, 4, 2, 1, 0),    # critic block: 4 stride phases in the input-gradient table
+              (2, 128, 8, 8, 64, 3, 3, 1, 1, 1),      # generator conv behind the fused upsample
+              (2, 3, 32, 32, 64, 7, 7, 2, 3, 0),      # classifier stem: K = 147, padded tables
+              (2, 72, 8, 8, 40, 3, 3, 1, 1, 0),       # Cout = 40: padded columns
+              (2, 512, 4, 4, 1, 4, 4, 1, 0, 0)]       # critic head: one output row
+    params = []
+    for key in shapes:
+        plan = ops.get_plan(key, dev)
+        w = torch.nn.Parameter(torch.randn(key[4], key[1], key[5], key[6], generator=g).to(dev))
+        for mode in (CONV_FWD, CONV_DGRAD):
+            ops._packed_weights(plan.noups() if mode == CONV_DGRAD else plan, w, mode)
+        params.append((plan, w))
+    with torch.no_grad():
+        for _, w in params:
+            w.mul_(-1.5).add_(0.25)
+    ops.repack_cached([w for _, w in params], None)
+    torch.cuda.synchronize()
+    n = 0
+    for plan, w in params:
+        for wkey, hit in w._sempyr_pack.items():
+            pl, mode = hit[5], hit[6]
+            fresh = torch.full_like(hit[1], float('nan'))
+            ops.check(ops.L.sempyr_conv2d_pack_weights(pl.desc_ref, mode, w.data_ptr(), pl.mode(mode).wsrc.data_ptr(), fresh.data_ptr(),
+                                                       ops._stream()), "sempyr_conv2d_pack_weights")
+            assert torch.equal(hit[1], fresh), (pl.key, mode)
+            n += 1
+    assert n == 2 * len(shapes)
