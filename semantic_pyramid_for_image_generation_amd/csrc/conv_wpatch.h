@@ -1,8 +1,8 @@
 // Included by conv_igemm.hip inside its anonymous namespace.
 //
-// Weight gradient of 3x3 / stride 1 / pad 1 (optionally behind the fused nearest upsample) and 4x4 / stride 2 / pad 1
-// convolutions with a LONG reduction and few output tiles -- the generator's 256^2 / 128^2 blocks (generator.py:41-43) and
-// the critic's first block (discriminator.py:105) -- as an LDS row-ring kernel:
+// Weight gradient of 3x3 / stride 1 / pad 1 convolutions (optionally behind the fused nearest upsample) with a LONG
+// reduction and few output blocks -- the generator's 64^2 ... 256^2 layers (generator.py:41-43) -- as an LDS row-ring
+// kernel; a 4x4 / stride 2 / pad 1 instance (the critic's first block, discriminator.py:105) exists as an opt-in:
 //
 //     gw[co][ci][kh][kw] = sum over (n, oy, ox) of gy[n][co][oy][ox] * x[n][ci][S*oy - 1 + kh][S*ox - 1 + kw]
 //
@@ -10,17 +10,21 @@
 // tap operands with its own global gather, so an input element crosses the memory system T times (measured 5.08x the
 // algorithmic bytes on 64 -> 64 @ 256^2).  Here a workgroup owns a 64 (co) x 64 (ci) x T block of the result and walks a
 // "slab" of the reduction: consecutive output rows of one column strip (CW pixels wide) of one sample.  Per output row it
-// stages ONE row segment of gy (64 co x CW) and only the S NEW source rows (64 ci x (S*CW + KW - S)) -- the other KH - S
-// rows of the tap window are still in the ring from the previous step -- so an input element is fetched
-// (S*CW + KW - S) / (S*CW) ~ 1.03x.  All T tap operands of a k-step are shifted views of the ring:
+// stages ONE row segment of gy (64 co x CW) and only the S NEW source rows -- the other KH - S rows of the tap window are
+// still in the ring from the previous steps.  A source row segment (columns cb - 1 ... cb + S*CW) is fetched as aligned
+// float4 from column cb - 4 on (18 instead of 16.5 float4 per channel; the unused head and tail land in slack words of
+// the LDS row), so a thread issues 5 wide loads per row instead of 17 dword loads.  All T tap operands of a k-step are
+// shifted views of the ring:
 //
 //     wave (wco, wci) holds T accumulator blocks of 32 co x 32 ci; per pair of adjacent pixels: one ds_read_b32 of gy (the A
 //     operand, shared by the T taps) + T ds_read_b32 of the ring feed T v_mfma_f32_32x32x2_f32.
 //
 // Rows are padded to odd pitches, so the 32 lanes of an operand (32 channels, same pixel) hit 32 different banks.  The next
-// step's rows are loaded into registers before the current step's MFMAs and stored into the free ring slots / the other gy
-// buffer behind them: one barrier per output row.  Every slab writes its block of partial sums in the generic kernel's slab
-// layout [slab][co][tap * Cin + ci]; the library's split-K combine kernels (fixed order) finish the job.
+// step's float4 are loaded one per pixel pair behind the first pairs' MFMAs and stored into the free ring slots / the other
+// gy buffer behind the last pairs': one barrier per output row, and neither the vector-memory issue nor the LDS stores hold
+// the matrix pipe up for long (a row step runs at 0.95 of its MFMA-only time).  Every slab writes its block of partial sums
+// in the generic kernel's slab layout [slab][co][tap * Cin + ci]; the library's split-K combine kernels (fixed order)
+// finish the job.  Measurements: DESIGN.md 5.12.
 struct WpParams {
     const float* gy; const float* x; float* out;
     long long slab_stride;
