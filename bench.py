@@ -252,7 +252,8 @@ def main():
     timing = not a.no_kernel_timing
     if a.profile_pass:
         cycle(lookahead=False)          # (no stage A of a captured iteration left in flight)
-        ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = ops.PREFETCH = False
+        ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops.PREFETCH = False
+        ops.SIDE_ON_MAIN = True         # (the product's weight-gradient kernels, issued on the one stream)
         lp.use_graphs = False
         cycle()
         barrier()
@@ -349,8 +350,9 @@ def main():
         cycle(lookahead=False)          # (untimed: no stage A of a captured iteration left in flight when the mode changes)
         barrier()
         # single-stream for this pass: a kernel's event-to-event time is only its own duration when nothing else shares the GPU
-        saved = (ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH)
-        ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops._ASYNC_ENV = ops.PREFETCH = False
+        saved = (ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops.SIDE_ON_MAIN, ops.PREFETCH)
+        ops.TWO_STREAM_CRITIC = ops.TWO_STREAM_GENERATOR = ops.PREFETCH = False
+        ops.SIDE_ON_MAIN = True         # (the product's weight-gradient kernels, issued on the one stream)
         saved_graphs, lp.use_graphs = lp.use_graphs, False          # event pairs are recorded by the launch functions: issue eagerly
         _lib.check(_lib.lib.sempyr_profile_begin(4096 * max(a.steps, 1)), "sempyr_profile_begin")
         t1 = time.perf_counter()
@@ -360,7 +362,7 @@ def main():
         elapsed_instr = time.perf_counter() - t1
         _lib.check(_lib.lib.sempyr_profile_end(ctypes.byref(kms), ctypes.byref(kl), ctypes.byref(kf)), "sempyr_profile_end")
         hbm_rows = hbm_report(a.steps)
-        ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops._ASYNC_ENV, ops.PREFETCH = saved
+        ops.TWO_STREAM_CRITIC, ops.TWO_STREAM_GENERATOR, ops.SIDE_ON_MAIN, ops.PREFETCH = saved
         lp.use_graphs = saved_graphs
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if torch.distributed.get_backend() == 'gloo' else device)

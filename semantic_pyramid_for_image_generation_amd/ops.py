@@ -121,6 +121,9 @@ class input_grads_only:
 # backward passes (no create_graph) take this route; SEMPYR_ASYNC_WGRAD=0 turns it off.
 _ASYNC_ENV = os.environ.get("SEMPYR_ASYNC_WGRAD", "1") != "0"
 _ASYNC_ON = False
+# measurement aid (bench.py's single-stream passes): the same kernels -- gradients accumulated by the combine kernels, no
+# AccumulateGrad adds -- issued on the CURRENT stream, so that a kernel's event-to-event time is its own duration
+SIDE_ON_MAIN = False
 _SIDE = {}
 _SIDE_DIRTY = set()
 
@@ -313,8 +316,9 @@ def _param_grads_async(gy, x, plan, w, bias, want_w, want_b, bsrc=None):
     """WGRAD(gy, x) -> w.grad and channel_sum(gy) -> bias.grad on the side stream."""
     dev = gy.device
     main = _current_stream_obj(dev)
-    side = _side_stream(dev)
-    side.wait_stream(main)
+    side = main if SIDE_ON_MAIN else _side_stream(dev)
+    if side is not main:
+        side.wait_stream(main)
     torch.cuda.set_stream(side)            # (the `with torch.cuda.stream(...)` context costs ~40 us of host time)
     try:
         # a weight used by several passes of one step (D(real,fake), D(x_hat)): later contributions are added to .grad by
@@ -338,9 +342,10 @@ def _param_grads_async(gy, x, plan, w, bias, want_w, want_b, bsrc=None):
             _GRAD_ISSUED_HOOK(w)
     finally:
         torch.cuda.set_stream(main)
-    gy.record_stream(side)
-    x.record_stream(side)
-    _SIDE_DIRTY.add(dev.index)
+    if side is not main:
+        gy.record_stream(side)
+        x.record_stream(side)
+        _SIDE_DIRTY.add(dev.index)
 
 
 def _can_async(w, bias, want_w, want_b):

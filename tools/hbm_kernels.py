@@ -41,7 +41,7 @@ for k in lib["kernels"]:
                 "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 0), "frac_of_peak": round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 3)})
 res.sort(key=lambda r: -r["rocprof_ms_per_cycle"])
 covered = set(x for k in lib["kernels"] for x in match(k["kernel"]))
-conv = ('igemm_kernel', 'patch3x3', 'tpatch_kernel', 'wpatch_kernel', 'rgb3x3', 'gather_small_m', 'rgb_wgrad3x3', 'sempyr_marker')
+conv = ('igemm_kernel', 'patch3x3', 'tpatch_kernel', 'wpatch_kernel', 'rgb3x3', 'gather_small_m', 'small_m_cmajor', 'rgb_wgrad3x3', 'sempyr_marker')
 rest = sorted(((k, v) for k, v in dur.items() if k not in covered and not any(c in k for c in conv)), key=lambda kv: -kv[1][1])
 for r in res:
     print('%-36s n/cycle %6.1f  %9.3f MB  %8.2f us  %6.3f ms/cycle  %6.0f GB/s  %.3f' % (

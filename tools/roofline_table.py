@@ -13,7 +13,7 @@ import collections, csv, json, re, sys
 
 trace, launches, out = sys.argv[1], sys.argv[2], sys.argv[3]
 PEAK = 157.3
-CONV = ('igemm_kernel', 'patch3x3_kernel', 'tpatch_kernel', 'wpatch_kernel', 'rgb3x3_kernel', 'gather_small_m_kernel', 'rgb_wgrad3x3_kernel')
+CONV = ('igemm_kernel', 'patch3x3_kernel', 'tpatch_kernel', 'wpatch_kernel', 'rgb3x3_kernel', 'gather_small_m_kernel', 'small_m_cmajor_kernel', 'rgb_wgrad3x3_kernel')
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 marks = [i for i, r in enumerate(rows) if 'sempyr_marker_kernel' in r['Kernel_Name']]
@@ -26,7 +26,7 @@ assert len(conv) == len(recs), (len(conv), len(recs))
 
 
 def short(name):
-    m = re.search(r'(igemm_kernel|patch3x3_kernel|tpatch_kernel|wpatch_kernel|rgb3x3_kernel|gather_small_m_kernel|rgb_wgrad3x3_kernel)(<[^>]*>)?', name)
+    m = re.search(r'(igemm_kernel|patch3x3_kernel|tpatch_kernel|wpatch_kernel|rgb3x3_kernel|gather_small_m_kernel|small_m_cmajor_kernel|rgb_wgrad3x3_kernel)(<[^>]*>)?', name)
     return (m.group(1) + (m.group(2) or '')) if m else name[:60]
 
 

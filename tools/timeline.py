@@ -9,7 +9,7 @@ marks = [i for i, r in enumerate(rows) if 'marker' in r['Kernel_Name']]
 a, b = marks[0], marks[-1]
 t0, t1 = int(rows[a]['End_Timestamp']), int(rows[b]['Start_Timestamp'])
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows[a + 1:b]]
-isconv = lambda n: any(k in n for k in ('igemm_kernel', 'patch3x3', 'tpatch_kernel', 'wpatch_kernel', 'rgb3x3', 'gather_small', 'rgb_wgrad3x3', 'stem3x3'))
+isconv = lambda n: any(k in n for k in ('igemm_kernel', 'patch3x3', 'tpatch_kernel', 'wpatch_kernel', 'rgb3x3', 'gather_small', 'small_m_cmajor', 'rgb_wgrad3x3', 'stem3x3'))
 def short(n):
     n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'^void ', '', n)
     m = re.match(r'at::native::\w+<[^,]*, at::native::(\w+)', n)
