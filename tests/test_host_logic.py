@@ -95,3 +95,20 @@ def test_make_grid_layout():
     assert float(grid.max()) == 1.0 and float(grid[:, :2].abs().max()) == 0.0
     assert torch.allclose(grid[:, 2:6, 2:7], (x[0] - x.min()) / (x.max() - x.min()))
     assert torch.allclose(grid[:, 8:12, 9:14], (x[9] - x.min()) / (x.max() - x.min()))
+
+
+def test_loader_read_ahead_pairs():
+    """train_model._with_next: every batch is prepared exactly once and handed to the loop together with the batches of the
+    next calls (what TrainLoop.iteration(next_images=...) launches stage A for), in loader order"""
+    from semantic_pyramid_for_image_generation_amd.train_model import _with_next
+    seen = []
+
+    def prep(x):
+        seen.append(x)
+        return x * 10
+
+    assert list(_with_next(range(5), prep, 2)) == [(0, [10, 20]), (10, [20, 30]), (20, [30, 40]), (30, [40]), (40, None)]
+    assert seen == [0, 1, 2, 3, 4]
+    assert list(_with_next(range(3), prep, 1)) == [(0, [10]), (10, [20]), (20, None)]
+    assert list(_with_next([7], prep, 3)) == [(70, None)]
+    assert list(_with_next([], prep, 1)) == []
