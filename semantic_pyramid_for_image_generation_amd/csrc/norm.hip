@@ -773,6 +773,76 @@ __global__ __launch_bounds__(256) void instnorm_fwd_reg_kernel(const float* __re
     }
 }
 
+// Training-mode BatchNorm of a SMALL layer (N * HW <= 16384 elements per channel: the generator's 4^2 ... 32^2 blocks at
+// batch 16) in ONE launch: a workgroup owns a channel, keeps its N rows in registers (NV4 float4 per thread, all loads in
+// flight together), reduces mean and centred second moment over the whole channel, updates the running statistics and applies
+// scale / shift / activation.  The three-launch form (row moments -> finalize -> apply) spends ~14 us of launch latency on
+// tensors of 16 KB ... 1 MB, in a chain in front of the next convolution.
+// APPLY = false: the statistics / coefficient step alone (residual tails apply two norms in one pass of their own); `rep`: the
+// tensor stands for one in which every element occurs `rep` times (see norm_finalize_kernel).
+template <int NV4, bool APPLY>
+__global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* __restrict__ x, int N, int C, int HW, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* running_mean, float* running_var, long long* nbt, float momentum,
+                                                           float rep, int act, float slope, float* __restrict__ y, float* __restrict__ rowbuf)
+{
+    __shared__ float sh[8];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int q = HW >> 2;                          // float4 per row
+    const int items = N * q;
+    float4 v[NV4];
+    size_t off[NV4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int it = t + i * 256;
+        const bool live = it < items;
+        const int n = live ? it / q : 0, e = live ? it - n * q : 0;
+        off[i] = ((size_t)n * C + c) * HW + 4 * (size_t)e;
+        v[i] = live ? *reinterpret_cast<const float4*>(x + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s[1] = {0.f};
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) s[0] += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    row_reduce<256, 1>(s, sh);
+    const float m = (float)N * (float)HW;
+    const float mean = s[0] / m;
+    __syncthreads();
+    float r[1] = {0.f};
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        if (t + i * 256 < items) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            r[0] += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    row_reduce<256, 1>(r, sh);
+    const float m2 = r[0];
+    const float var = m2 / m;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = rstd * gamma[c], sf = beta[c];
+    const int rows = N * C;
+    for (int b = t; b < N; b += 256) {
+        const int row = b * C + c;
+        rowbuf[row] = mean; rowbuf[rows + row] = rstd; rowbuf[2 * rows + row] = sc; rowbuf[3 * rows + row] = sf;
+    }
+    if (t == 0 && running_mean) {
+        const float unbiased = m * rep > 1.f ? (m2 * rep) / (m * rep - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        if (c == 0 && nbt) *nbt += 1;
+    }
+    if constexpr (!APPLY) return;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        if (t + i * 256 < items) {
+            float4 o;
+            o.x = act_apply((v[i].x - mean) * sc + sf, act, slope); o.y = act_apply((v[i].y - mean) * sc + sf, act, slope);
+            o.z = act_apply((v[i].z - mean) * sc + sf, act, slope); o.w = act_apply((v[i].w - mean) * sc + sf, act, slope);
+            *reinterpret_cast<float4*>(y + off[i]) = o;
+        }
+    }
+}
+
 template <int TPR, int NV4>
 __global__ __launch_bounds__(256) void instnorm_bwd_reg_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                const float* __restrict__ x, const float* __restrict__ gamma,
@@ -882,6 +952,30 @@ __global__ __launch_bounds__(256) void norm_bwd_channel_kernel(const float* __re
 
 } // namespace
 
+// one-launch training-mode BatchNorm of small layers (bn_fwd_small_kernel); SEMPYR_BN_SMALL=0: the multi-launch form (A/B aid)
+inline bool bn_small_ok(int kind, int N, int HW, const float* x) {
+    static const bool on = !(getenv("SEMPYR_BN_SMALL") && getenv("SEMPYR_BN_SMALL")[0] == '0');
+    return on && kind == SEMPYR_NORM_BATCH && HW % 4 == 0 && (long long)N * HW <= 16384 && aligned16(x);
+}
+template <bool APPLY>
+int launch_bn_small(const float* x, int N, int C, int HW, float eps, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* nbt, float momentum, int rep, int act, float slope, float* y, float* rowbuf,
+                    hipStream_t st)
+{
+    const int items = N * (HW / 4);
+    int nv4 = 1;
+    while (nv4 * 256 < items) nv4 *= 2;
+    switch (nv4) {
+#define SEMPYR_CASE(NV) case NV: hipLaunchKernelGGL((bn_fwd_small_kernel<NV, APPLY>), dim3(C), dim3(256), 0, st, x, N, C, HW, eps, gamma, beta, \
+                                                    running_mean, running_var, (long long*)nbt, momentum, (float)rep, act, slope, y, rowbuf); break;
+        SEMPYR_CASE(1) SEMPYR_CASE(2) SEMPYR_CASE(4) SEMPYR_CASE(8) SEMPYR_CASE(16)
+#undef SEMPYR_CASE
+        default: SEMPYR_FAIL("norm: internal: %d float4 per thread", nv4);
+    }
+    SEMPYR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW, float eps,
                                  const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
@@ -892,6 +986,11 @@ extern "C" int sempyr_norm_stats(int kind, const float* x, int N, int C, int HW,
     if (rep < 1) SEMPYR_FAIL("norm_stats: replication factor %d", rep);
     hipStream_t st = (hipStream_t)stream;
     const int rows = N * C;
+    if (bn_small_ok(kind, N, HW, x)) {
+        HbmScope hs("bn_fwd_small_kernel", 4.0 * rows * HW, st);
+        return launch_bn_small<false>(x, N, C, HW, eps, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, rep,
+                                      0, 0.f, nullptr, rowbuf, st);
+    }
     const int vec = (HW % 4 == 0) && aligned16(x);
     float* rmean = scratch; float* rm2 = scratch + rows;
     {
@@ -951,6 +1050,11 @@ extern "C" int sempyr_norm_fwd(int kind, const float* x, int N, int C, int HW, f
         else hipLaunchKernelGGL(instnorm_fwd_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, rows, C, HW, vec, eps, gamma, beta, act, slope, y, rowbuf);
         SEMPYR_CHECK_LAUNCH();
         return 0;
+    }
+    if (bn_small_ok(kind, N, HW, x) && aligned16(y)) {
+        HbmScope hs("bn_fwd_small_kernel", 8.0 * rows * HW, (hipStream_t)stream);
+        return launch_bn_small<true>(x, N, C, HW, eps, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, 1, act, slope,
+                                     y, rowbuf, (hipStream_t)stream);
     }
     if (int rc = sempyr_norm_stats(kind, x, N, C, HW, eps, gamma, beta, running_mean, running_var, num_batches_tracked,
                                    momentum, 1, rowbuf, scratch, stream)) return rc;
