@@ -8,6 +8,8 @@ tolerances, checked here against the same oracles:
     within the north star's 1e-3;
   * parameter gradients of those steps: within the measured-noise bound of tests/test_steps_gpu.py (3x the distance of the fp32
     CPU runs from fp64) widened by BF16X3_GRAD_FACTOR -- the split keeps 16 significant bits per operand, not 24."""
+import copy
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -84,15 +86,24 @@ def test_generator_images_and_steps_within_1e3(dev):
         crit = tm.L1Loss()
         real = (images - 0.5) / 0.5
         refs32 = T._fp32_runs(tr, lambda t: t.d_step(T.j(real), T.j(feats), masks, T.j(z), alpha))
+        d64_before = {k: v.detach().clone() for k, v in tr.d.items()}
         want = tr.d_step(T._d(real), T._d(feats), T._d(masks), T._d(z), T._d(alpha))
-        got = tm.train_discriminator(G, D, d_loss_fn, T._Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999)), real.to(dev),
-                                     [f.to(dev) for f in feats], [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
+        d_before = copy.deepcopy(D.state_dict())
+        with T._CaptureLine(tm) as cap:
+            got = tm.train_discriminator(G, D, d_loss_fn, T._Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999)), real.to(dev),
+                                         [f.to(dev) for f in feats], [m.to(dev) for m in masks], z=z.to(dev), alpha=alpha.to(dev))
         for k in want:
             assert abs(float(got[k].detach()) - float(want[k])) <= 1e-3 * max(1.0, abs(float(want[k]))), k
+        grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in D.named_parameters()}
+        # a LeakyReLU pre-activation at round-off distance from zero that lands on the other side: as in test_steps_gpu (the fake
+        # batch differs from the fp32 path's by ~1e-5 here, so WHICH elements do is a draw of its own)
+        flips, dist = T._lrelu_flips(D, d_before, d64_before, 'instance_norm', 'res', real, cap, dev)
+        print(f"[bf16x3-d] LeakyReLU pre-activations that changed side: {flips} (largest {dist:.1e} of the tensor maximum)")
+        assert dist < 1e-4, f"{flips} LeakyReLU signs differ from fp64, one at {dist:.1e} of its tensor's maximum: not round-off"
         saved = dict(T.ALLOW)
         try:
             T.ALLOW[('bf16x3-d', '')] = ('factor', BF16X3_GRAD_FACTOR)
-            T._grads_close({k: p.grad for k, p in D.named_parameters()}, tr.d, [r.d for r in refs32], tr.d_params, 'bf16x3-d')
+            T._grads_close(grads, tr.d, [r.d for r in refs32], tr.d_params, 'bf16x3-d', widen=10.0 if flips else 1.0)
         finally:
             T.ALLOW.clear(); T.ALLOW.update(saved)
 
