@@ -710,9 +710,11 @@ def _main():
             # (a pinned host batch goes to the loop as it is: the upload is issued on the loop's prefetch stream, in front of
             # the work that reads it, instead of on this stream behind the previous iteration's backward pass.  The loop is
             # also given the NEXT batch: it launches that iteration's stage A ahead of this one's stage B -- never across a
-            # generator step, so the sampling / checkpoint blocks below (iterations % 1000 == 1, generator-step iterations)
-            # see no work in flight that reads or writes the two networks)
+            # generator step, and not in the iterations that end in the sampling / checkpoint blocks below, which must see no
+            # work in flight that reads the generator or updates its BatchNorm buffers)
             images = data
+            if iterations % 1000 == 1:
+                data_next = None          # this iteration samples from / checkpoints the networks below: nothing in flight meanwhile
             out = loop.iteration(images, log=writer is not None, next_images=data_next)
             if first_iter and rank == 0:
                 first_iter = False
