@@ -713,8 +713,10 @@ def _main():
             # generator step, and not in the iterations that end in the sampling / checkpoint blocks below, which must see no
             # work in flight that reads the generator or updates its BatchNorm buffers)
             images = data
-            if iterations % 1000 == 1:
-                data_next = None          # this iteration samples from / checkpoints the networks below: nothing in flight meanwhile
+            # the next iteration that samples from / checkpoints the networks below: nothing behind it may be in flight then
+            to_sampling = (1 - iterations) % 1000
+            if data_next is not None:
+                data_next = data_next[:to_sampling] or None
             out = loop.iteration(images, log=writer is not None, next_images=data_next)
             if first_iter and rank == 0:
                 first_iter = False
